@@ -1,0 +1,181 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY, CONTAINER-ONLY.  Writes tests/golden/*.npz from the REAL reference.
+
+Run from the repo root:  ``python -m oracle.gen_golden``  (needs /root/reference; ~2 min on 8 cores).
+
+Every fixture is data: seeds + architecture numbers + inputs + outputs of the reference's own code
+(``forward`` M:1927, ``prepare_inputs_for_generation`` M:2081, ``build/apply_delay_pattern_mask``
+M:68-139, driven by ``oracle/ref_shim.reference_generate_ids``), or of the installed transformers
+``T5EncoderModel`` / ``DacModel`` for the third-party arithmetic.  Weights are NOT stored: they are
+re-created from the seed by ``parler_tts_amd.weights.synthetic_state_dict`` (numpy PCG64, platform
+independent), which is also how the reference model was loaded here.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import ref_shim  # noqa: E402
+from parler_tts_amd.configuration import mini_v01_config, tiny_config  # noqa: E402
+from parler_tts_amd.weights import synthetic_state_dict  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **_np(arrays))
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def synth_inputs(cfg, B, T, P, seed, ragged=False):
+    g = torch.Generator().manual_seed(seed)
+    hi = min(32100, cfg.text_encoder.vocab_size)
+    desc = torch.randint(2, hi, (B, T), generator=g)
+    prompt = torch.randint(2, min(32100, cfg.vocab_size), (B, P), generator=g)
+    amask = torch.ones(B, T, dtype=torch.long)
+    pmask = torch.ones(B, P, dtype=torch.long)
+    if ragged:
+        for b in range(B):
+            nd = int(torch.randint(0, T // 2, (1,), generator=g))
+            npad = int(torch.randint(0, P // 2 + 1, (1,), generator=g))
+            if nd:
+                amask[b, T - nd:] = 0      # descriptions right-padded
+                desc[b, T - nd:] = 0
+            if npad:
+                pmask[b, :npad] = 0        # prompts LEFT-padded (training script T:916)
+                prompt[b, :npad] = 0
+    return desc, amask, prompt, pmask
+
+
+def delay_mask_cases(ref):
+    cases = []
+    g = torch.Generator().manual_seed(7)
+    for (B, K, L, s) in [(1, 4, 8, 1), (2, 9, 40, 1), (3, 9, 17, 1), (2, 9, 16, 1), (2, 4, 12, 3), (1, 9, 30, 5),
+                         (2, 2, 3, 1), (1, 9, 2580, 1)]:
+        bos, pad = 1025, 1024
+        ids = torch.randint(0, 1024, (B * K, s), generator=g)
+        ids[:, 0] = bos
+        cut, pat = ref.build_delay_pattern_mask(ids.clone(), bos, pad, L, K)
+        applied = ref.apply_delay_pattern_mask(torch.randint(0, 1024, (B * K, min(L, s + 5)), generator=g), pat)
+        cases.append(dict(B=B, K=K, L=L, s=s, ids=ids, cut=cut, pattern=pat, applied=applied))
+    flat = {}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            flat[f"c{i}_{k}"] = v
+    flat["n_cases"] = len(cases)
+    save("delay_masks", **flat)
+
+
+def free_margin(r):
+    """smallest top-2 logit gap over the argmaxes whose token is actually kept (pattern == -1)"""
+    if "margins" not in r:
+        return float("inf")
+    m = r["margins"]
+    free = (r["pattern"][:, 1:1 + m.shape[0]] == -1).T
+    return float(m[free].min()) if bool(free.any()) else float("inf")
+
+
+_models = {}
+
+
+def run_case(name, cfg, sd_kw, B, T, P, L, seed_in, ragged=False, pass_prompt_mask=False, record=0,
+             min_margin=0.0, **gen):
+    """``min_margin``: input seeds are scanned (seed_in, seed_in+1000, ...) until every kept greedy
+    argmax of the reference run has a top-2 gap above it, so that bit-exact token parity is a fair
+    demand on an implementation whose fp32 sums are ordered differently."""
+    key = (id(cfg), json.dumps(sd_kw, sort_keys=True))
+    if key not in _models:
+        sd = synthetic_state_dict(cfg, parts=("text_encoder", "decoder"), **sd_kw)
+        _models[key] = ref_shim.build_reference_model(cfg, sd)
+    model = _models[key]
+    for attempt in range(40):
+        desc, amask, prompt, pmask = synth_inputs(cfg, B, T, P, seed_in, ragged)
+        use_pmask = pmask if (ragged or pass_prompt_mask) else None
+        r = ref_shim.reference_generate_ids(model, desc, amask, prompt, use_pmask, L, record_logits=record, **gen)
+        fm = free_margin(r)
+        if fm >= min_margin:
+            break
+        print(f"  {name}: seed_in={seed_in} free-min margin {fm:.2e} < {min_margin:.0e}, trying next seed")
+        seed_in += 1000
+    else:
+        raise RuntimeError("no seed met the margin")
+    print(f"  {name}: seed_in={seed_in} free-min margin {fm:.3e}")
+    arrays = dict(desc=desc, amask=amask, prompt=prompt, pmask=pmask, has_pmask=int(use_pmask is not None),
+                  max_length=L, free_min_margin=fm, **{k: v for k, v in r.items()})
+    arrays["meta"] = json.dumps(dict(sd_kw=sd_kw, B=B, T=T, P=P, L=L, seed_in=seed_in, ragged=ragged,
+                                     gen={k: (v if not isinstance(v, dict) else "forced") for k, v in gen.items()
+                                          if k != "generator"}))
+    if "forced_tokens" in gen and gen["forced_tokens"]:
+        ft = gen["forced_tokens"]
+        arrays["forced_steps"] = np.array(sorted(ft.keys()))
+        arrays["forced_vals"] = torch.stack([ft[s] for s in sorted(ft.keys())])
+    save(name, **arrays)
+    r["seed_in"] = seed_in
+    return r
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = ref_shim.load_reference()
+
+    # ---- (1) integer path: delay masks straight from the reference functions (M:68-139)
+    delay_mask_cases(ref)
+
+    # ---- (2) sinusoid table from the reference class (M:199-213)
+    tab = ref.modeling_parler_tts.ParlerTTSSinusoidalPositionalEmbedding.get_embedding(96, 128)
+    save("sinusoid", table=tab)
+
+    tiny = tiny_config()
+    kw = dict(seed=11, never_eos=True, ln_jitter=0.1)
+    # ---- (3) tiny greedy, equal lengths, no prompt mask: all steps' logits recorded
+    run_case("tiny_greedy", tiny, kw, B=3, T=9, P=5, L=24, seed_in=100, record=64, min_margin=1e-3)
+    # ---- (4) tiny greedy, ragged (right-padded descriptions, left-padded prompts)
+    run_case("tiny_greedy_ragged", tiny, kw, B=4, T=10, P=6, L=20, seed_in=101, ragged=True, record=64, min_margin=1e-3)
+    # ---- (5) tiny with a live EOS row: heads may emit 64 (=eos=pad); plus a forced EOS while a
+    #          codebook is still inside its BOS region (latching quirk, SURVEY 8a note (i))
+    kw_eos = dict(seed=12, never_eos=False, ln_jitter=0.1)
+    K = tiny.decoder.num_codebooks
+    r0 = run_case("tiny_eos_free", tiny, kw_eos, B=3, T=9, P=5, L=30, seed_in=102, record=64, min_margin=5e-4)
+    ft = r0["raw_ids"][:, 2].clone()       # tokens chosen at step 1 ...
+    ft[1 * K + 3] = tiny.decoder.eos_token_id   # ... but utterance 1 / codebook 3 emits EOS while forced-BOS
+    ft[2 * K + 0] = tiny.decoder.eos_token_id   # and utterance 2 / codebook 0 ends right away
+    run_case("tiny_eos_forced", tiny, kw_eos, B=3, T=9, P=5, L=30, seed_in=r0["seed_in"], record=64, forced_tokens={1: ft})
+    # ---- (6) tiny classifier-free guidance (next-row f.1), greedy
+    run_case("tiny_cfg", tiny, kw, B=2, T=9, P=5, L=20, seed_in=103, record=64, guidance_scale=3.0, min_margin=1e-3)
+    # ---- (7) tiny sampling: teacher-forced along the reference's own sampled path; the fixture holds
+    #          the per-step logits (pre-warper) and the sampled ids under torch's CPU generator
+    g = torch.Generator().manual_seed(2024)
+    run_case("tiny_sample", tiny, kw, B=3, T=9, P=5, L=24, seed_in=104, record=64, do_sample=True,
+             temperature=0.7, top_k=50, generator=g)
+
+    # ---- (8) mini_v0.1 dimensions (24 x 1024, K=9, flan-t5-base sized encoder), short horizon
+    mini = mini_v01_config()
+    kwm = dict(seed=21, never_eos=True, ln_jitter=0.0)
+    run_case("mini_greedy", mini, kwm, B=2, T=12, P=6, L=24, seed_in=11200, record=6, min_margin=1e-3)
+    run_case("mini_greedy_ragged", mini, kwm, B=2, T=12, P=6, L=20, seed_in=201, ragged=True, record=4, min_margin=1e-3)
+
+    # ---- (9) codec decode vs the installed transformers DacModel (structural oracle)
+    for name, cfg, seed, B, Fr in (("dac_tiny", tiny, 11, 2, 7), ("dac_mini", mini, 21, 1, 6)):
+        sd = synthetic_state_dict(cfg, seed=seed, parts=("audio_encoder",))
+        hf = ref_shim.build_hf_dac(cfg, sd)
+        gg = torch.Generator().manual_seed(5)
+        codes = torch.randint(0, cfg.audio_encoder.codebook_size, (B, cfg.audio_encoder.num_codebooks, Fr), generator=gg)
+        with torch.no_grad():
+            z = hf.quantizer.from_codes(codes)[0]
+            wav = hf.decoder(z)
+        save(name, codes=codes, latent=z, wav=wav, seed=seed)
+
+
+if __name__ == "__main__":
+    main()
