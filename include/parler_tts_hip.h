@@ -1,0 +1,160 @@
+/*
+ * parler_tts_hip.h - C ABI of the MI355X (gfx950) Parler-TTS generate() engine.
+ *
+ * The reference (danlyth/parler-tts) has no FFI layer: its boundary is the Python API
+ * `ParlerTTSForConditionalGeneration.generate()` (parler_tts/modeling_parler_tts.py:2342-2686).
+ * `parler_tts_amd/modeling.py` keeps that Python API and drives the hot path through the entry points
+ * below (ctypes; see INTEGRATION.md for the binding a maintainer of the reference would add).
+ * Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in _host
+ *   - tensors are caller-owned; the engine owns only its packed weights, the paged KV pools and
+ *     workspaces (allocated in ptts_create / ptts_prepare, never in the per-step calls)
+ *   - every call that launches work is asynchronous on `stream` (a hipStream_t passed as void*)
+ *   - return value: 0 = ok, negative = PTTS_E_* ; ptts_last_error() gives the text (HIP error
+ *     strings included); no exceptions cross the ABI
+ *   - one engine per device; not thread-safe per engine, re-entrant across engines
+ */
+#ifndef PARLER_TTS_HIP_H
+#define PARLER_TTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTTS_ABI_VERSION 1
+
+enum { PTTS_DTYPE_F32 = 0, PTTS_DTYPE_BF16 = 1 };
+
+enum {
+    PTTS_OK = 0,
+    PTTS_E_INVALID = -1,    /* bad argument / shape */
+    PTTS_E_STATE = -2,      /* call order (weights missing, prefill not run, ...) */
+    PTTS_E_HIP = -3,        /* a HIP runtime call failed */
+    PTTS_E_NOMEM = -4,
+    PTTS_E_UNSUPPORTED = -5
+};
+
+/* Architecture numbers: ParlerTTSDecoderConfig (configuration_parler_tts.py:82-127), the T5 encoder
+ * config, DACConfig (dac_wrapper/configuration_dac.py:8-25). */
+typedef struct ptts_config {
+    int32_t abi_version;        /* PTTS_ABI_VERSION */
+    int32_t dtype;              /* weights + KV cache storage: PTTS_DTYPE_*; accumulation is always fp32 */
+    /* decoder */
+    int32_t hidden, layers, heads, ffn, vocab, codebooks, max_positions;
+    int32_t pad_token_id, eos_token_id, bos_token_id;
+    /* composite */
+    int32_t prompt_vocab;       /* rows of embed_prompts */
+    int32_t enc_hidden;         /* T5 d_model (enc_to_dec_proj exists iff enc_hidden != hidden) */
+    /* T5 encoder */
+    int32_t t5_layers, t5_heads, t5_dkv, t5_dff, t5_vocab, t5_gated, t5_act; /* act: 1 gelu, 2 gelu_new, 3 relu */
+    float t5_eps;
+    /* limits used to size pools/workspaces */
+    int32_t max_batch;          /* utterances per call (x2 internally under classifier-free guidance) */
+    int32_t max_desc_len;       /* T */
+    int32_t max_prompt_len;     /* P */
+    int32_t max_length;         /* generation columns L (<= max_positions - P) */
+} ptts_config;
+
+typedef struct ptts_engine ptts_engine;
+
+const char* ptts_last_error(void);
+int ptts_abi_version(void);
+
+/* ---- lifetime ---- */
+int ptts_create(const ptts_config* cfg, ptts_engine** out);
+int ptts_destroy(ptts_engine* e);
+
+/* Hand one fp32 tensor of the reference state dict (key layout: SURVEY.md 8b) to the engine, which
+ * re-tiles / converts it into its own HBM layout (packed MFMA tiles, bf16 tables).  `data` may be
+ * freed after the stream has drained.  Replaces nn.Module parameter ownership
+ * (modeling_parler_tts.py:760-781, 1069-1071, 1635-1642). */
+int ptts_load_tensor(ptts_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim,
+                     void* stream);
+/* 0 when every tensor of the decoder (+T5 when t5_layers > 0) has arrived; otherwise PTTS_E_STATE and the
+ * first missing names in ptts_last_error(). */
+int ptts_weights_ready(ptts_engine* e);
+
+/* ---- text encoder: T5EncoderModel(input_ids, attention_mask).last_hidden_state
+ *      (called at modeling_parler_tts.py:2229).  rel_bias [t5_heads][2T-1] is the bucketed relative
+ *      position bias gathered by the host (index j - i + T - 1).  out: [B][T][enc_hidden] fp32. ---- */
+int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_ids, const int32_t* attention_mask,
+                   const float* rel_bias, float* out, void* stream);
+
+/* ---- prefill: everything generate() does before the token loop (modeling_parler_tts.py:2467-2537)
+ *      plus the first forward pass over the prompt (decoder forward M:794-978 with P+1 positions):
+ *      enc_to_dec_proj + mask (M:2010-2017), cross K/V of every layer (M:295-298), prompt embedding
+ *      (M:2243-2245), the P prompt positions through the self-attention cache.
+ *      B_eff rows are fed (= 2B under classifier-free guidance: the caller passes the zeroed "null"
+ *      half exactly as M:2231-2237 builds it).
+ *        enc_states   [B_eff][T][enc_hidden] fp32      attention_mask [B_eff][T] int32 (never NULL)
+ *        prompt_ids   [B_eff][P] int64 (P may be 0)    prompt_mask [B_eff][P] int32 or NULL
+ *        pattern      [B*K][L] int64 delay pattern (build_delay_pattern_mask, M:77-139)
+ *        raw_ids      [B*K][L] int64 caller-owned output; column 0.. are filled by decode steps
+ *      After it, StepState = {pos = P, cur_len = first free column}. ---- */
+int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P, int32_t L,
+                 const float* enc_states, const int32_t* attention_mask, const int64_t* prompt_ids,
+                 const int32_t* prompt_mask, const int64_t* pattern, int64_t* raw_ids, int32_t start_len,
+                 void* stream);
+
+/* Sampling parameters of the third-party GenerationMixin step the reference calls at
+ * modeling_parler_tts.py:2582 (greedy) / :2608 (sample).  */
+typedef struct ptts_sampling {
+    int32_t do_sample;       /* 0: argmax */
+    float temperature;       /* scores / temperature */
+    int32_t top_k;           /* 0 = off */
+    float guidance_scale;    /* > 1: rows [0,B*K) conditional, [B*K,2B*K) unconditional (M:2556-2558) */
+    uint64_t seed;           /* Philox key; draws are (seed, row, step) so runs are reproducible */
+} ptts_sampling;
+
+/* ---- decode: n_steps iterations of {prepare_inputs_for_generation (M:2081-2148), forward
+ *      (M:1927-2079 -> M:794-978 -> M:1096-1185), token selection, pad-out of finished rows, EOS
+ *      latch}.  State stays on the device; steps are replayed from a captured hipGraph.
+ *      profile_every > 0: every profile_every-th step is launched eagerly with HIP events around the
+ *      self-attention kernels (read back with ptts_profile_read). ---- */
+int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, int32_t profile_every, void* stream);
+
+/* Loop state (host copy; synchronises `stream`): cur_len, unfinished rows, the column count at which
+ * every row had finished (0 = not yet), steps run. */
+typedef struct ptts_state {
+    int32_t pos, cur_len, prompt_len, n_unfinished, done_len, step_count;
+} ptts_state;
+int ptts_get_state(ptts_engine* e, ptts_state* out_host, void* stream);
+
+/* logits of the last executed step [B_eff*K][vocab] fp32 (device pointer owned by the engine), for
+ * parity tests; probabilities after warping when sampling. */
+int ptts_last_logits(ptts_engine* e, const float** logits, const float** probs);
+
+/* Override the identity page table of the self-attention KV pool: table [max_batch_eff][max_blocks]
+ * int32 of distinct page ids < n_pages (tests shuffle it; results must not change). */
+int ptts_set_block_table(ptts_engine* e, const int32_t* table_host, int32_t rows, int32_t max_blocks);
+int ptts_pool_info(ptts_engine* e, int32_t* n_pages, int32_t* max_blocks, int64_t* page_bytes);
+
+/* Test hook (teacher forcing): tokens_host [B*K] int64; a value >= 0 replaces the next steps' selected
+ * token of that row before the pad-out / EOS latch, -1 leaves the row alone; NULL clears.  While set,
+ * steps are launched eagerly. */
+int ptts_set_forced_tokens(ptts_engine* e, const int64_t* tokens_host, int32_t rows);
+
+/* HIP-event profile of the dominant kernel (self-attention decode): sums over the sampled launches. */
+typedef struct ptts_profile {
+    int64_t launches;        /* sampled self-attention launches */
+    double total_ms;         /* sum of their durations */
+    double algo_bytes;       /* sum of their algorithmic bytes: 2 * B_eff * S * hidden * sizeof(cache elem) */
+    int64_t steps;           /* sampled steps */
+    double step_ms;          /* sum of the sampled steps' durations (eager) */
+} ptts_profile;
+int ptts_profile_read(ptts_engine* e, ptts_profile* out_host, int32_t reset);
+
+/* Stand-alone kernels exposed for unit tests (same code paths the engine uses). */
+int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* W, const float* X, int32_t prologue,
+                   const float* gamma, const float* beta, float eps, int32_t act, const float* bias, float* Y,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARLER_TTS_HIP_H */

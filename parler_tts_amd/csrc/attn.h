@@ -1,0 +1,34 @@
+// Host-side interface of attn.hip (internal).
+#pragma once
+#include "ptts_common.h"
+#include "gemm.h"
+
+struct AttnArgs {
+    const float* q = nullptr;     // [B][ldq] fp32, already scaled
+    int ldq = 0;
+    KVPool pool = {};
+    int layer = 0;
+    int len = 0;                  // number of keys when !len_from_state
+    int len_from_state = 0;       // 1: keys = state->pos + 1 (self attention, after this step's append)
+    const StepState* state = nullptr;
+    const float* bias = nullptr;  // additive mask [B][ld_bias] (0 / finfo.min) or null
+    int ld_bias = 0;
+    int s_cap = 0;                // LDS score capacity (>= max keys, multiple of 4)
+    void* ofrag = nullptr;        // output in B-fragment order, feature count D
+    int D = 0;
+};
+
+struct FullAttnArgs {
+    const float* qkv = nullptr;   // [B*T][ld] rows = [q | k | v], each H*dk wide
+    int ld = 0;
+    int T = 0, H = 0, dk = 0;
+    float scale = 1.0f;
+    const float* rel_bias = nullptr;  // [H][n_rel], index (j - i + T - 1)
+    int n_rel = 0;
+    const int* mask = nullptr;        // [B][T] 1 = attend
+    void* ofrag = nullptr;
+};
+
+hipError_t attn_init();
+hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream);
+hipError_t attn_full_launch(const FullAttnArgs& a, int B, int out_dtype, hipStream_t stream);

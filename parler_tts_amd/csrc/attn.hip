@@ -1,0 +1,256 @@
+// Single-query attention over the paged KV pool (decode step) and small full attention (T5 encoder).
+//
+// attn_decode: one workgroup per (head, utterance); the query is one token (reference M:264-382 with
+// tgt_len = 1; q was already scaled by hd^-0.5 in the projection epilogue, M:282).  HBM-bound: the
+// workgroup streams S x 64 K values and S x 64 V values exactly once.
+//   * K/V rows are 64 elements (128 B bf16 / 256 B fp32).  A wave64 `global_load_dwordx4` covers
+//     TPW = 8 (bf16) / 4 (fp32) consecutive tokens = 1 KiB contiguous inside a 64-token page;
+//     UNR such loads are issued back-to-back per wave before the first use.
+//   * pass 1: scores s_t = q.k_t (+ additive mask, 0 or finfo.min as the reference adds it, M:339)
+//     -> LDS; lanes of a token reduce with wave shuffles
+//   * softmax over the whole row in fp32 exactly as torch does it (max, exp, sum, divide; M:342)
+//   * pass 2: o = sum_t p_t v_t accumulated per lane, reduced across token-lanes and waves (LDS)
+//   * output is written in MFMA B-fragment order for the out_proj GEMM (gemm.hip PRO_FRAG)
+// The number of cached tokens comes from device memory (StepState.pos) so that one captured
+// hipGraph serves every step.
+#include "ptts_common.h"
+#include "attn.h"
+
+namespace {
+
+constexpr int NWAVES = 4;
+constexpr int UNR = 8;
+
+template <typename P> struct KVLoad;
+template <> struct KVLoad<PBF16> {
+    static constexpr int LPT = 8;   // lanes per token row
+    static constexpr int EPL = 8;
+    typedef u32x4 raw_t;
+    static __device__ inline void unpack(const raw_t& r, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+            f[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+        }
+    }
+};
+template <> struct KVLoad<PF32> {
+    static constexpr int LPT = 16;
+    static constexpr int EPL = 4;
+    typedef u32x4 raw_t;
+    static __device__ inline void unpack(const raw_t& r, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, r[i]);
+    }
+};
+
+template <typename P, typename OP>
+__global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
+    typedef typename P::elem_t elem_t;
+    typedef KVLoad<P> L;
+    constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);                   // [S_cap] scores -> probabilities
+    float* red = sc + a.s_cap;                                    // [NWAVES][64] partial outputs
+    float* wred = red + NWAVES * 64;                              // [NWAVES] cross-wave scalars
+    int* pages = reinterpret_cast<int*>(wred + NWAVES);           // [max_blocks] this utterance's page ids
+
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int S = a.len_from_state ? (a.state->pos + 1) : a.len;
+    const int tt = lane / LPT, c = lane % LPT;                    // token-in-tile, 16-byte chunk of the row
+    const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
+
+    float q[EPL];
+    {
+        const float* qp = a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) q[j] = qp[j];
+    }
+    const float* bias = a.bias ? a.bias + (size_t)b * a.ld_bias : nullptr;
+    // page ids once into LDS: KV addresses then depend on no global load
+    for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[b * a.pool.max_blocks + i];
+    __syncthreads();
+    const size_t page_elems = a.pool.page_elems();
+    auto kv_off = [&](int kv, int tok) -> size_t {
+        return (size_t)pages[tok >> 6] * page_elems +
+               ((size_t)((a.layer * 2 + kv) * a.pool.H + h) * PTTS_PAGE_TOKENS + (tok & 63)) * PTTS_HEAD_DIM;
+    };
+
+    // ---------------- pass 1: scores ----------------
+    const int ntiles = (S + TPW - 1) / TPW;
+    for (int t0 = w; t0 < ntiles; t0 += NWAVES * UNR) {
+        typename L::raw_t kr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int tile = t0 + u * NWAVES;
+            int tok = tile * TPW + tt;
+            if (tok > S - 1) tok = S - 1;
+            kr[u] = *reinterpret_cast<const typename L::raw_t*>(pool + kv_off(0, tok) + c * EPL);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int tile = t0 + u * NWAVES;
+            int tok = tile * TPW + tt;
+            float kf[EPL];
+            L::unpack(kr[u], kf);
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) d = fmaf(q[j], kf[j], d);
+#pragma unroll
+            for (int o = 1; o < LPT; o <<= 1) d += __shfl_xor(d, o);
+            if (c == 0 && tok < S) sc[tok] = bias ? d + bias[tok] : d;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- softmax over [0, S) ----------------
+    float m = -INFINITY;
+    for (int t = tid; t < S; t += NWAVES * 64) m = fmaxf(m, sc[t]);
+    m = wave_max(m);
+    if (lane == 0) wred[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = tid; t < S; t += NWAVES * 64) {
+        float e = expf(sc[t] - m);
+        sc[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) wred[w] = sum;
+    __syncthreads();
+    sum = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+    for (int t = tid; t < S; t += NWAVES * 64) sc[t] = sc[t] / sum;
+    __syncthreads();
+
+    // ---------------- pass 2: o = P.V ----------------
+    float acc[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
+    for (int t0 = w; t0 < ntiles; t0 += NWAVES * UNR) {
+        typename L::raw_t vr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int tok = (t0 + u * NWAVES) * TPW + tt;
+            if (tok > S - 1) tok = S - 1;
+            vr[u] = *reinterpret_cast<const typename L::raw_t*>(pool + kv_off(1, tok) + c * EPL);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int tok = (t0 + u * NWAVES) * TPW + tt;
+            float p = (tok < S) ? sc[tok] : 0.f;
+            float vf[EPL];
+            L::unpack(vr[u], vf);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+        }
+    }
+    // lanes with equal c hold partial sums for the same 16-byte chunk: fold the token-lanes
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
+    }
+    if (tt == 0) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) red[w * 64 + c * EPL + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < PTTS_HEAD_DIM) {
+        float o = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(b >> 5) * 32 * a.D;
+        of[frag_off<OP>(b & 31, h * PTTS_HEAD_DIM + tid)] = to_elem<OP>(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Full (bidirectional) attention for the T5 encoder: T <= 512 tokens, one workgroup per (head, b).
+// scores = q.k (no scaling) + rel-pos bias[h][bucket(j - i)] + (1 - mask_j) * finfo.min; softmax fp32.
+// (HF:models/t5/modeling_t5.py:144-173, 217-280.)  q/k/v row-major fp32 [B*T][3*inner] as written by
+// the QKV projection; output in fragment order for the `o` projection.
+// ------------------------------------------------------------------------------------------------
+template <typename OP>
+__global__ __launch_bounds__(256) void attn_full_kernel(FullAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = a.T, dk = a.dk;
+    float* ks = reinterpret_cast<float*>(smem);          // [T][dk+1]
+    float* vs = ks + T * (dk + 1);                       // [T][dk+1]
+    float* pr = vs + T * (dk + 1);                       // [4 waves][T] probabilities of the wave's query
+    float* qs = pr + 4 * T;                              // [4][dk]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int inner = a.H * dk;
+    const float* base = a.qkv + (size_t)b * T * a.ld;
+    for (int i = tid; i < T * dk; i += 256) {
+        int t = i / dk, d = i % dk;
+        ks[t * (dk + 1) + d] = base[(size_t)t * a.ld + inner + h * dk + d];
+        vs[t * (dk + 1) + d] = base[(size_t)t * a.ld + 2 * inner + h * dk + d];
+    }
+    __syncthreads();
+    const int* mask = a.mask ? a.mask + (size_t)b * T : nullptr;
+    for (int qi = w; qi < T; qi += 4) {
+        for (int d = lane; d < dk; d += 64) qs[w * dk + d] = base[(size_t)qi * a.ld + h * dk + d];
+        __builtin_amdgcn_wave_barrier();
+        float mx = -INFINITY;
+        for (int j = lane; j < T; j += 64) {
+            float s = 0.f;
+            for (int d = 0; d < dk; ++d) s = fmaf(qs[w * dk + d], ks[j * (dk + 1) + d], s);
+            s = s * a.scale;
+            s = s + a.rel_bias[(size_t)h * a.n_rel + (j - qi + T - 1)];
+            if (mask) s = s + (1.0f - (float)mask[j]) * -3.4028234663852886e38f;
+            pr[w * T + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < T; j += 64) {
+            float e = expf(pr[w * T + j] - mx);
+            pr[w * T + j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < dk; d += 64) {
+            float o = 0.f;
+            for (int j = 0; j < T; ++j) o = fmaf(pr[w * T + j] / sum, vs[j * (dk + 1) + d], o);
+            int row = b * T + qi;
+            typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(row >> 5) * 32 * inner;
+            of[frag_off<OP>(row & 31, h * dk + d)] = to_elem<OP>(o);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+hipError_t attn_init() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PBF16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PF32>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream) {
+    size_t lds = ((size_t)a.s_cap + NWAVES * 64 + NWAVES + a.pool.max_blocks) * sizeof(float);
+    dim3 grid(H, B), block(NWAVES * 64);
+    if (cache_dtype == PTTS_BF16) {
+        if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_decode_kernel<PBF16, PBF16>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<PBF16, PF32>), grid, block, lds, stream, a);
+    } else {
+        if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_decode_kernel<PF32, PBF16>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<PF32, PF32>), grid, block, lds, stream, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t attn_full_launch(const FullAttnArgs& a, int B, int out_dtype, hipStream_t stream) {
+    size_t lds = ((size_t)2 * a.T * (a.dk + 1) + 4 * a.T + 4 * a.dk) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid(a.H, B), block(256);
+    if (out_dtype == PTTS_BF16) hipLaunchKernelGGL(attn_full_kernel<PBF16>, grid, block, lds, stream, a);
+    else hipLaunchKernelGGL(attn_full_kernel<PF32>, grid, block, lds, stream, a);
+    return hipGetLastError();
+}

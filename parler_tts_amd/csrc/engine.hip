@@ -1,0 +1,767 @@
+// C ABI of the engine (include/parler_tts_hip.h): weight registry, paged KV pools, the decode-step
+// launch sequence (captured once into a hipGraph and replayed per token), prefill, T5 encoder,
+// HIP-event profiling of the dominant kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/parler_tts_hip.h"
+#include "attn.h"
+#include "gemm.h"
+#include "misc.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(PTTS_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define PTTS_TRY(expr)            \
+    do {                          \
+        int _r = (expr);          \
+        if (_r != PTTS_OK) return _r; \
+    } while (0)
+
+struct Packed {
+    void* ptr = nullptr;
+    int N = 0, K = 0;
+};
+
+struct DecLayer {
+    Packed qkv, o, cq, ckv, co, fc1, fc2;
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
+};
+struct T5Layer {
+    Packed qkv, o, wi, wo;
+    float *ln0 = nullptr, *ln1 = nullptr;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    double bytes;
+    int kind;  // 0 = self-attention launch, 1 = whole step
+};
+
+}  // namespace
+
+struct ptts_engine {
+    ptts_config cfg;
+    int dt = 0;
+    size_t esz = 4;
+    int Vp = 0;  // per-head vocab padded to 16
+    std::vector<void*> allocs;
+    std::set<std::string> loaded;
+    // decoder weights
+    std::vector<DecLayer> layers;
+    Packed heads, enc_proj;
+    float *lnf_g = nullptr, *lnf_b = nullptr, *enc_proj_bias = nullptr;
+    void *embed_tokens = nullptr, *pos_table = nullptr, *embed_prompts = nullptr;
+    // T5
+    std::vector<T5Layer> t5;
+    void* t5_shared = nullptr;
+    float* t5_final_ln = nullptr;
+    // pools
+    void *self_pool = nullptr, *cross_pool = nullptr;
+    int *self_table = nullptr, *cross_table = nullptr;
+    int self_blocks = 0, cross_blocks = 0, self_pages = 0;
+    // workspaces
+    int mtiles = 1;
+    float *x = nullptr, *q = nullptr, *logits = nullptr, *probs = nullptr, *enc_h = nullptr;
+    void *attn_frag = nullptr, *mlp_frag = nullptr;
+    float *self_bias = nullptr, *cross_bias = nullptr;
+    int s_cap = 0;
+    bool has_self_bias = false;
+    int *tok_in = nullptr, *unfinished = nullptr, *unf_count = nullptr;
+    long long* force = nullptr;
+    bool use_force = false;
+    StepState* state = nullptr;
+    // T5 workspaces
+    float *t5_x = nullptr, *t5_qkv = nullptr;
+    void *t5_afrag = nullptr, *t5_ffrag = nullptr;
+    // per-call
+    bool prefilled = false;
+    int B = 0, B_eff = 0, T = 0, P = 0, L = 0;
+    const long long* pattern = nullptr;
+    long long* raw_ids = nullptr;
+    const long long* prompt_ids = nullptr;
+    int host_pos = 0, host_cur = 0;
+    // graphs
+    hipGraphExec_t step_graph = nullptr;
+    ptts_sampling graph_sp = {};
+    bool no_graph = false;
+    // profile
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    ptts_profile prof = {};
+};
+
+namespace {
+
+int dev_alloc(ptts_engine* e, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t r = hipMalloc(p, bytes);
+    if (r != hipSuccess) return fail(PTTS_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(r));
+    e->allocs.push_back(*p);
+    return PTTS_OK;
+}
+
+KVPool make_pool(const ptts_engine* e, bool cross) {
+    KVPool p;
+    p.base = cross ? e->cross_pool : e->self_pool;
+    p.block_table = cross ? e->cross_table : e->self_table;
+    p.max_blocks = cross ? e->cross_blocks : e->self_blocks;
+    p.H = e->cfg.heads;
+    p.L = e->cfg.layers;
+    return p;
+}
+
+int launch_gemm(ptts_engine* e, const GemmArgs& a, hipStream_t s) {
+    int v = gemm_validate(a, e->dt);
+    if (v != 0) return fail(PTTS_E_INVALID, "gemm shape rejected (code %d): M=%d N=%d K=%d pro=%d epi=%d", v, a.M, a.N, a.K, a.pro, a.epi);
+    HIP_TRY(gemm_launch(a, e->dt, s));
+    return PTTS_OK;
+}
+
+bool parse_idx(const std::string& name, const std::string& prefix, int* idx, std::string* rest) {
+    if (name.compare(0, prefix.size(), prefix) != 0) return false;
+    size_t p = prefix.size(), q = name.find('.', p);
+    if (q == std::string::npos) return false;
+    *idx = atoi(name.substr(p, q - p).c_str());
+    *rest = name.substr(q + 1);
+    return true;
+}
+
+int ensure_packed(ptts_engine* e, Packed* w, int N, int K) {
+    if (w->ptr) return PTTS_OK;
+    int Np = (N + 15) / 16 * 16;
+    PTTS_TRY(dev_alloc(e, &w->ptr, (size_t)Np * K * e->esz));
+    HIP_TRY(hipMemset(w->ptr, 0, (size_t)Np * K * e->esz));
+    w->N = Np;
+    w->K = K;
+    return PTTS_OK;
+}
+
+int load_packed(ptts_engine* e, Packed* w, int Ntot, int K, int n_off, int n_stride, const float* data, const int64_t* shape,
+                int ndim, int Nsrc, hipStream_t s) {
+    if (ndim != 2 || shape[0] != Nsrc || shape[1] != K)
+        return fail(PTTS_E_INVALID, "weight shape mismatch: expected [%d,%d]", Nsrc, K);
+    PTTS_TRY(ensure_packed(e, w, Ntot, K));
+    HIP_TRY(pack_weight_launch(data, w->ptr, Nsrc, K, n_off, n_stride, e->dt, s));
+    return PTTS_OK;
+}
+
+int load_f32(ptts_engine* e, float** dst, size_t n, const float* data, const int64_t* shape, int ndim, hipStream_t s) {
+    size_t have = 1;
+    for (int i = 0; i < ndim; ++i) have *= (size_t)shape[i];
+    if (have != n) return fail(PTTS_E_INVALID, "vector size mismatch: expected %zu got %zu", n, have);
+    if (!*dst) PTTS_TRY(dev_alloc(e, (void**)dst, n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(*dst, data, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return PTTS_OK;
+}
+
+int load_table(ptts_engine* e, void** dst, size_t total, size_t off, size_t n, const float* data, hipStream_t s) {
+    if (!*dst) PTTS_TRY(dev_alloc(e, dst, total * e->esz));
+    HIP_TRY(convert_launch(data, (char*)*dst + off * e->esz, n, e->dt, s));
+    return PTTS_OK;
+}
+
+// ---- one decoder layer stack over B_eff rows at the current position (decode token or prompt token) ----
+int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
+    const ptts_config& c = e->cfg;
+    const int D = c.hidden, F = c.ffn, M = e->B_eff;
+    const float scale = 1.0f / sqrtf((float)PTTS_HEAD_DIM);
+    for (int l = 0; l < c.layers; ++l) {
+        DecLayer& w = e->layers[l];
+        GemmArgs g;
+        // LN1 + fused QKV projection; q scaled (M:282), k/v appended to the paged cache (M:299-304)
+        g = GemmArgs();
+        g.W = w.qkv.ptr; g.N = 3 * D; g.K = D; g.M = M;
+        g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.eps = 1e-5f;
+        g.epi = EPI_QKV_SELF; g.out = e->q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
+        g.state = e->state; g.D = D;
+        PTTS_TRY(launch_gemm(e, g, s));
+        // self attention over pos+1 cached tokens
+        AttnArgs a;
+        a.q = e->q; a.ldq = D; a.pool = make_pool(e, false); a.layer = l; a.len_from_state = 1; a.state = e->state;
+        a.bias = e->has_self_bias ? e->self_bias : nullptr; a.ld_bias = e->s_cap; a.s_cap = e->s_cap;
+        a.ofrag = e->attn_frag; a.D = D;
+        EventPair* ep = nullptr;
+        if (profile && e->ev_used < e->ev_pool.size()) {
+            ep = &e->ev_pool[e->ev_used++];
+            ep->kind = 0;
+            ep->bytes = 2.0 * M * (double)(e->host_pos + 1) * D * (double)e->esz;
+            HIP_TRY(hipEventRecord(ep->a, s));
+        }
+        HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
+        if (ep) HIP_TRY(hipEventRecord(ep->b, s));
+        // out_proj + residual (M:380, M:460)
+        g = GemmArgs();
+        g.W = w.o.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        PTTS_TRY(launch_gemm(e, g, s));
+        // LN2 + cross-attention query (M:467-471)
+        g = GemmArgs();
+        g.W = w.cq.ptr; g.N = D; g.K = D; g.M = M;
+        g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.eps = 1e-5f;
+        g.epi = EPI_Q_SCALE; g.out = e->q; g.ldo = D; g.scale = scale;
+        PTTS_TRY(launch_gemm(e, g, s));
+        // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294)
+        a = AttnArgs();
+        a.q = e->q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
+        a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS;
+        a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = e->attn_frag; a.D = D;
+        HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
+        g = GemmArgs();
+        g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        PTTS_TRY(launch_gemm(e, g, s));
+        // LN3 + fc1 + GELU(erf) -> fragments ; fc2 + residual (M:486-492)
+        g = GemmArgs();
+        g.W = w.fc1.ptr; g.N = F; g.K = D; g.M = M;
+        g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.eps = 1e-5f;
+        g.epi = EPI_ACT_FRAG; g.act = ACT_GELU; g.ofrag = e->mlp_frag; g.ldo = F;
+        PTTS_TRY(launch_gemm(e, g, s));
+        g = GemmArgs();
+        g.W = w.fc2.ptr; g.N = D; g.K = F; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->mlp_frag;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        PTTS_TRY(launch_gemm(e, g, s));
+    }
+    return PTTS_OK;
+}
+
+EmbedArgs embed_args(ptts_engine* e) {
+    EmbedArgs a;
+    a.tables = e->embed_tokens; a.rows = e->cfg.vocab + 1; a.K = e->cfg.codebooks; a.D = e->cfg.hidden;
+    a.pos_table = e->pos_table; a.tok_in = e->tok_in; a.prompt_table = e->embed_prompts;
+    a.prompt_ids = e->prompt_ids; a.P = e->P; a.state = e->state; a.x = e->x;
+    return a;
+}
+
+int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool profile) {
+    const ptts_config& c = e->cfg;
+    EventPair* step_ev = nullptr;
+    if (profile && e->ev_used < e->ev_pool.size()) {
+        step_ev = &e->ev_pool[e->ev_used++];
+        step_ev->kind = 1; step_ev->bytes = 0;
+        HIP_TRY(hipEventRecord(step_ev->a, s));
+    }
+    HIP_TRY(embed_codebooks_launch(embed_args(e), e->B_eff, e->dt, s));
+    PTTS_TRY(run_layers(e, s, profile));
+    // final LayerNorm (M:959) + the K LM heads (M:1143) -> logits [B_eff][K][Vp]
+    GemmArgs g;
+    g.W = e->heads.ptr; g.N = c.codebooks * e->Vp; g.K = c.hidden; g.M = e->B_eff;
+    g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = c.hidden; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.eps = 1e-5f;
+    g.epi = EPI_ROWMAJOR; g.out = e->logits; g.ldo = c.codebooks * e->Vp;
+    PTTS_TRY(launch_gemm(e, g, s));
+    SelectArgs sa;
+    sa.logits = e->logits; sa.rows = e->B * c.codebooks; sa.V = e->Vp; sa.vocab = c.vocab; sa.L = e->L; sa.state = e->state;
+    sa.raw_ids = e->raw_ids; sa.pattern = e->pattern; sa.unfinished = e->unfinished; sa.unf_count = e->unf_count;
+    sa.tok_in = e->tok_in; sa.force = e->use_force ? e->force : nullptr; sa.probs = e->probs;
+    sa.pad = c.pad_token_id; sa.eos = c.eos_token_id; sa.do_sample = sp.do_sample; sa.top_k = sp.top_k;
+    sa.temperature = sp.temperature; sa.guidance = sp.guidance_scale; sa.seed = sp.seed;
+    HIP_TRY(select_launch(sa, s));
+    HIP_TRY(advance_launch(e->state, e->unf_count, e->L, s));
+    if (step_ev) HIP_TRY(hipEventRecord(step_ev->b, s));
+    return PTTS_OK;
+}
+
+bool same_sampling(const ptts_sampling& a, const ptts_sampling& b) {
+    return a.do_sample == b.do_sample && a.temperature == b.temperature && a.top_k == b.top_k &&
+           a.guidance_scale == b.guidance_scale && a.seed == b.seed;
+}
+
+void drop_graph(ptts_engine* e) {
+    if (e->step_graph) {
+        (void)hipGraphExecDestroy(e->step_graph);
+        e->step_graph = nullptr;
+    }
+}
+
+int capture_step_graph(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
+    drop_graph(e);
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int r = run_decode_step(e, sp, s, false);
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (r != PTTS_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return r;
+    }
+    if (ce != hipSuccess) return fail(PTTS_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    hipError_t ie = hipGraphInstantiate(&e->step_graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) {
+        e->step_graph = nullptr;
+        return fail(PTTS_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    }
+    e->graph_sp = sp;
+    return PTTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ptts_last_error(void) { return g_err.c_str(); }
+int ptts_abi_version(void) { return PTTS_ABI_VERSION; }
+
+int ptts_create(const ptts_config* cfg, ptts_engine** out) {
+    if (!cfg || !out) return fail(PTTS_E_INVALID, "null argument");
+    if (cfg->abi_version != PTTS_ABI_VERSION) return fail(PTTS_E_INVALID, "ABI version %d != %d", cfg->abi_version, PTTS_ABI_VERSION);
+    if (cfg->dtype != PTTS_DTYPE_F32 && cfg->dtype != PTTS_DTYPE_BF16) return fail(PTTS_E_INVALID, "dtype must be 0 (f32) or 1 (bf16)");
+    if (cfg->hidden <= 0 || cfg->hidden % 64 != 0 || cfg->heads * PTTS_HEAD_DIM != cfg->hidden)
+        return fail(PTTS_E_UNSUPPORTED, "hidden=%d heads=%d: head_dim must be 64", cfg->hidden, cfg->heads);
+    if (cfg->ffn % 32 != 0 || cfg->enc_hidden % 32 != 0) return fail(PTTS_E_UNSUPPORTED, "ffn / enc_hidden must be multiples of 32");
+    if (cfg->hidden > (cfg->dtype == PTTS_DTYPE_BF16 ? 2048 : 1024))
+        return fail(PTTS_E_UNSUPPORTED, "hidden=%d exceeds the LDS-resident LayerNorm row (2048 bf16 / 1024 f32)", cfg->hidden);
+    if (cfg->max_batch <= 0 || cfg->max_length <= 1 || cfg->max_desc_len <= 0 || cfg->max_prompt_len < 0)
+        return fail(PTTS_E_INVALID, "bad limits");
+    if (cfg->max_prompt_len + cfg->max_length > cfg->max_positions)
+        return fail(PTTS_E_INVALID, "max_prompt_len + max_length = %d exceeds max_positions = %d", cfg->max_prompt_len + cfg->max_length, cfg->max_positions);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PTTS_E_HIP, "no HIP device visible");
+    HIP_TRY(gemm_init());
+    HIP_TRY(attn_init());
+    ptts_engine* e = new ptts_engine();
+    e->cfg = *cfg;
+    e->dt = cfg->dtype;
+    e->esz = cfg->dtype == PTTS_DTYPE_BF16 ? 2 : 4;
+    e->Vp = (cfg->vocab + 15) / 16 * 16;
+    e->layers.resize(cfg->layers);
+    e->t5.resize(cfg->t5_layers > 0 ? cfg->t5_layers : 0);
+    e->no_graph = getenv("PTTS_NO_GRAPH") != nullptr;
+    const int Bm = cfg->max_batch, D = cfg->hidden, F = cfg->ffn, K = cfg->codebooks;
+    e->mtiles = (Bm + 31) / 32;
+    const int rows = e->mtiles * 32;
+    int rc = PTTS_OK;
+#define A(ptr, bytes) if (rc == PTTS_OK) rc = dev_alloc(e, (void**)&(ptr), (bytes))
+    // paged pools: page = [layers][2][heads][64 tok][64 dim]
+    e->self_blocks = (cfg->max_prompt_len + cfg->max_length + PTTS_PAGE_TOKENS - 1) / PTTS_PAGE_TOKENS;
+    e->cross_blocks = (cfg->max_desc_len + PTTS_PAGE_TOKENS - 1) / PTTS_PAGE_TOKENS;
+    e->self_pages = Bm * e->self_blocks;
+    const size_t page_bytes = (size_t)cfg->layers * 2 * cfg->heads * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM * e->esz;
+    A(e->self_pool, page_bytes * e->self_pages);
+    A(e->cross_pool, page_bytes * Bm * e->cross_blocks);
+    A(e->self_table, sizeof(int) * Bm * e->self_blocks);
+    A(e->cross_table, sizeof(int) * Bm * e->cross_blocks);
+    e->s_cap = e->self_blocks * PTTS_PAGE_TOKENS;
+    A(e->x, sizeof(float) * rows * D);
+    A(e->q, sizeof(float) * rows * D);
+    A(e->attn_frag, e->esz * rows * D);
+    A(e->mlp_frag, e->esz * rows * F);
+    A(e->logits, sizeof(float) * rows * K * e->Vp);
+    A(e->probs, sizeof(float) * rows * K * e->Vp);
+    A(e->self_bias, sizeof(float) * Bm * e->s_cap);
+    A(e->cross_bias, sizeof(float) * Bm * e->cross_blocks * PTTS_PAGE_TOKENS);
+    A(e->enc_h, sizeof(float) * ((size_t)Bm * cfg->max_desc_len + 32) * D);
+    A(e->tok_in, sizeof(int) * rows * K);
+    A(e->unfinished, sizeof(int) * rows * K);
+    A(e->unf_count, sizeof(int) * 4);
+    A(e->force, sizeof(long long) * rows * K);
+    A(e->state, sizeof(StepState));
+    if (cfg->t5_layers > 0) {
+        const int inner = cfg->t5_heads * cfg->t5_dkv;
+        const size_t trows = ((size_t)Bm * cfg->max_desc_len + 31) / 32 * 32;
+        A(e->t5_x, sizeof(float) * trows * cfg->enc_hidden);
+        A(e->t5_qkv, sizeof(float) * trows * 3 * inner);
+        A(e->t5_afrag, e->esz * trows * inner);
+        A(e->t5_ffrag, e->esz * trows * cfg->t5_dff);
+    }
+#undef A
+    if (rc != PTTS_OK) { ptts_destroy(e); return rc; }
+    // identity page tables
+    std::vector<int> tab(Bm * e->self_blocks);
+    for (size_t i = 0; i < tab.size(); ++i) tab[i] = (int)i;
+    hipError_t he = hipMemcpy(e->self_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice);
+    tab.resize(Bm * e->cross_blocks);
+    for (size_t i = 0; i < tab.size(); ++i) tab[i] = (int)i;
+    if (he == hipSuccess) he = hipMemcpy(e->cross_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemset(e->state, 0, sizeof(StepState));
+    if (he == hipSuccess) he = hipMemset(e->unf_count, 0, 4 * sizeof(int));
+    if (he == hipSuccess) he = hipMemset(e->attn_frag, 0, e->esz * rows * D);
+    if (he == hipSuccess) he = hipMemset(e->mlp_frag, 0, e->esz * rows * F);
+    if (he == hipSuccess) he = hipMemset(e->x, 0, sizeof(float) * rows * D);
+    if (he != hipSuccess) { ptts_destroy(e); return fail(PTTS_E_HIP, "init copies failed: %s", hipGetErrorString(he)); }
+    *out = e;
+    return PTTS_OK;
+}
+
+int ptts_destroy(ptts_engine* e) {
+    if (!e) return PTTS_OK;
+    drop_graph(e);
+    for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+    return PTTS_OK;
+}
+
+int ptts_load_tensor(ptts_engine* e, const char* cname, const float* data, const int64_t* shape, int32_t ndim, void* stream) {
+    if (!e || !cname || !data || !shape) return fail(PTTS_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const ptts_config& c = e->cfg;
+    const int D = c.hidden, F = c.ffn, V = c.vocab, K = c.codebooks;
+    std::string name(cname), rest;
+    int idx = 0, rc = PTTS_OK;
+    bool known = true;
+    if (parse_idx(name, "decoder.model.decoder.embed_tokens.", &idx, &rest) && rest == "weight") {
+        if (idx < 0 || idx >= K || ndim != 2 || shape[0] != V + 1 || shape[1] != D) return fail(PTTS_E_INVALID, "%s: bad shape", cname);
+        rc = load_table(e, &e->embed_tokens, (size_t)K * (V + 1) * D, (size_t)idx * (V + 1) * D, (size_t)(V + 1) * D, data, s);
+    } else if (name == "decoder.model.decoder.embed_positions.weights") {
+        if (ndim != 2 || shape[0] < c.max_positions || shape[1] != D) return fail(PTTS_E_INVALID, "%s: bad shape", cname);
+        rc = load_table(e, &e->pos_table, (size_t)c.max_positions * D, 0, (size_t)c.max_positions * D, data, s);
+    } else if (parse_idx(name, "decoder.model.decoder.layers.", &idx, &rest)) {
+        if (idx < 0 || idx >= c.layers) return fail(PTTS_E_INVALID, "%s: layer out of range", cname);
+        DecLayer& w = e->layers[idx];
+        if (rest == "self_attn.q_proj.weight") rc = load_packed(e, &w.qkv, 3 * D, D, 0, 1, data, shape, ndim, D, s);
+        else if (rest == "self_attn.k_proj.weight") rc = load_packed(e, &w.qkv, 3 * D, D, D, 1, data, shape, ndim, D, s);
+        else if (rest == "self_attn.v_proj.weight") rc = load_packed(e, &w.qkv, 3 * D, D, 2 * D, 1, data, shape, ndim, D, s);
+        else if (rest == "self_attn.out_proj.weight") rc = load_packed(e, &w.o, D, D, 0, 1, data, shape, ndim, D, s);
+        else if (rest == "encoder_attn.q_proj.weight") rc = load_packed(e, &w.cq, D, D, 0, 1, data, shape, ndim, D, s);
+        else if (rest == "encoder_attn.k_proj.weight") rc = load_packed(e, &w.ckv, 2 * D, D, 0, 1, data, shape, ndim, D, s);
+        else if (rest == "encoder_attn.v_proj.weight") rc = load_packed(e, &w.ckv, 2 * D, D, D, 1, data, shape, ndim, D, s);
+        else if (rest == "encoder_attn.out_proj.weight") rc = load_packed(e, &w.co, D, D, 0, 1, data, shape, ndim, D, s);
+        else if (rest == "fc1.weight") rc = load_packed(e, &w.fc1, F, D, 0, 1, data, shape, ndim, F, s);
+        else if (rest == "fc2.weight") rc = load_packed(e, &w.fc2, D, F, 0, 1, data, shape, ndim, D, s);
+        else if (rest == "self_attn_layer_norm.weight") rc = load_f32(e, &w.ln1_g, D, data, shape, ndim, s);
+        else if (rest == "self_attn_layer_norm.bias") rc = load_f32(e, &w.ln1_b, D, data, shape, ndim, s);
+        else if (rest == "encoder_attn_layer_norm.weight") rc = load_f32(e, &w.ln2_g, D, data, shape, ndim, s);
+        else if (rest == "encoder_attn_layer_norm.bias") rc = load_f32(e, &w.ln2_b, D, data, shape, ndim, s);
+        else if (rest == "final_layer_norm.weight") rc = load_f32(e, &w.ln3_g, D, data, shape, ndim, s);
+        else if (rest == "final_layer_norm.bias") rc = load_f32(e, &w.ln3_b, D, data, shape, ndim, s);
+        else known = false;
+    } else if (name == "decoder.model.decoder.layer_norm.weight") rc = load_f32(e, &e->lnf_g, D, data, shape, ndim, s);
+    else if (name == "decoder.model.decoder.layer_norm.bias") rc = load_f32(e, &e->lnf_b, D, data, shape, ndim, s);
+    else if (parse_idx(name, "decoder.lm_heads.", &idx, &rest) && rest == "weight") {
+        if (idx < 0 || idx >= K) return fail(PTTS_E_INVALID, "%s: head out of range", cname);
+        rc = load_packed(e, &e->heads, K * e->Vp, D, idx * e->Vp, 1, data, shape, ndim, V, s);
+    } else if (name == "enc_to_dec_proj.weight") rc = load_packed(e, &e->enc_proj, D, c.enc_hidden, 0, 1, data, shape, ndim, D, s);
+    else if (name == "enc_to_dec_proj.bias") rc = load_f32(e, &e->enc_proj_bias, D, data, shape, ndim, s);
+    else if (name == "embed_prompts.weight") {
+        if (ndim != 2 || shape[0] != c.prompt_vocab || shape[1] != D) return fail(PTTS_E_INVALID, "%s: bad shape", cname);
+        rc = load_table(e, &e->embed_prompts, (size_t)c.prompt_vocab * D, 0, (size_t)c.prompt_vocab * D, data, s);
+    } else if (name == "text_encoder.shared.weight") {
+        if (c.t5_layers <= 0) return PTTS_OK;
+        if (ndim != 2 || shape[0] != c.t5_vocab || shape[1] != c.enc_hidden) return fail(PTTS_E_INVALID, "%s: bad shape", cname);
+        rc = load_table(e, &e->t5_shared, (size_t)c.t5_vocab * c.enc_hidden, 0, (size_t)c.t5_vocab * c.enc_hidden, data, s);
+    } else if (name == "text_encoder.encoder.final_layer_norm.weight") {
+        if (c.t5_layers <= 0) return PTTS_OK;
+        rc = load_f32(e, &e->t5_final_ln, c.enc_hidden, data, shape, ndim, s);
+    } else if (parse_idx(name, "text_encoder.encoder.block.", &idx, &rest)) {
+        if (c.t5_layers <= 0) return PTTS_OK;
+        if (idx < 0 || idx >= c.t5_layers) return fail(PTTS_E_INVALID, "%s: block out of range", cname);
+        T5Layer& w = e->t5[idx];
+        const int inner = c.t5_heads * c.t5_dkv, d = c.enc_hidden, ff = c.t5_dff;
+        if (rest == "layer.0.SelfAttention.q.weight") rc = load_packed(e, &w.qkv, 3 * inner, d, 0, 1, data, shape, ndim, inner, s);
+        else if (rest == "layer.0.SelfAttention.k.weight") rc = load_packed(e, &w.qkv, 3 * inner, d, inner, 1, data, shape, ndim, inner, s);
+        else if (rest == "layer.0.SelfAttention.v.weight") rc = load_packed(e, &w.qkv, 3 * inner, d, 2 * inner, 1, data, shape, ndim, inner, s);
+        else if (rest == "layer.0.SelfAttention.o.weight") rc = load_packed(e, &w.o, d, inner, 0, 1, data, shape, ndim, d, s);
+        else if (rest == "layer.0.SelfAttention.relative_attention_bias.weight") rc = PTTS_OK;  // gathered by the host
+        else if (rest == "layer.0.layer_norm.weight") rc = load_f32(e, &w.ln0, d, data, shape, ndim, s);
+        else if (rest == "layer.1.layer_norm.weight") rc = load_f32(e, &w.ln1, d, data, shape, ndim, s);
+        else if (rest == "layer.1.DenseReluDense.wi_0.weight") rc = load_packed(e, &w.wi, 2 * ff, d, 0, 2, data, shape, ndim, ff, s);
+        else if (rest == "layer.1.DenseReluDense.wi_1.weight") rc = load_packed(e, &w.wi, 2 * ff, d, 16, 2, data, shape, ndim, ff, s);
+        else if (rest == "layer.1.DenseReluDense.wi.weight") rc = load_packed(e, &w.wi, ff, d, 0, 1, data, shape, ndim, ff, s);
+        else if (rest == "layer.1.DenseReluDense.wo.weight") rc = load_packed(e, &w.wo, d, ff, 0, 1, data, shape, ndim, d, s);
+        else known = false;
+    } else if (name.compare(0, 14, "audio_encoder.") == 0 || name == "text_encoder.encoder.embed_tokens.weight") {
+        return PTTS_OK;  // codec weights are not consumed by this library yet; tied T5 embedding alias
+    } else known = false;
+    if (!known) return fail(PTTS_E_INVALID, "unknown tensor name '%s'", cname);
+    if (rc == PTTS_OK) e->loaded.insert(name);
+    return rc;
+}
+
+int ptts_weights_ready(ptts_engine* e) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    const ptts_config& c = e->cfg;
+    std::vector<std::string> need;
+    char buf[256];
+    for (int k = 0; k < c.codebooks; ++k) {
+        snprintf(buf, sizeof buf, "decoder.model.decoder.embed_tokens.%d.weight", k); need.push_back(buf);
+        snprintf(buf, sizeof buf, "decoder.lm_heads.%d.weight", k); need.push_back(buf);
+    }
+    need.push_back("decoder.model.decoder.embed_positions.weights");
+    need.push_back("decoder.model.decoder.layer_norm.weight");
+    need.push_back("decoder.model.decoder.layer_norm.bias");
+    need.push_back("embed_prompts.weight");
+    if (c.enc_hidden != c.hidden) { need.push_back("enc_to_dec_proj.weight"); need.push_back("enc_to_dec_proj.bias"); }
+    const char* per_layer[] = {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.out_proj.weight",
+                               "encoder_attn.q_proj.weight", "encoder_attn.k_proj.weight", "encoder_attn.v_proj.weight",
+                               "encoder_attn.out_proj.weight", "fc1.weight", "fc2.weight", "self_attn_layer_norm.weight",
+                               "self_attn_layer_norm.bias", "encoder_attn_layer_norm.weight", "encoder_attn_layer_norm.bias",
+                               "final_layer_norm.weight", "final_layer_norm.bias"};
+    for (int l = 0; l < c.layers; ++l)
+        for (const char* p : per_layer) { snprintf(buf, sizeof buf, "decoder.model.decoder.layers.%d.%s", l, p); need.push_back(buf); }
+    if (c.t5_layers > 0) {
+        need.push_back("text_encoder.shared.weight");
+        need.push_back("text_encoder.encoder.final_layer_norm.weight");
+        for (int l = 0; l < c.t5_layers; ++l) {
+            const char* t5p[] = {"layer.0.SelfAttention.q.weight", "layer.0.SelfAttention.k.weight", "layer.0.SelfAttention.v.weight",
+                                 "layer.0.SelfAttention.o.weight", "layer.0.layer_norm.weight", "layer.1.layer_norm.weight",
+                                 "layer.1.DenseReluDense.wo.weight"};
+            for (const char* p : t5p) { snprintf(buf, sizeof buf, "text_encoder.encoder.block.%d.%s", l, p); need.push_back(buf); }
+            if (c.t5_gated) {
+                snprintf(buf, sizeof buf, "text_encoder.encoder.block.%d.layer.1.DenseReluDense.wi_0.weight", l); need.push_back(buf);
+                snprintf(buf, sizeof buf, "text_encoder.encoder.block.%d.layer.1.DenseReluDense.wi_1.weight", l); need.push_back(buf);
+            } else {
+                snprintf(buf, sizeof buf, "text_encoder.encoder.block.%d.layer.1.DenseReluDense.wi.weight", l); need.push_back(buf);
+            }
+        }
+    }
+    std::string missing;
+    int n = 0;
+    for (auto& k : need)
+        if (!e->loaded.count(k)) { if (n < 5) missing += (n ? ", " : "") + k; ++n; }
+    if (n) return fail(PTTS_E_STATE, "%d tensors missing: %s", n, missing.c_str());
+    return PTTS_OK;
+}
+
+int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_ids, const int32_t* attention_mask,
+                   const float* rel_bias, float* out, void* stream) {
+    if (!e || !input_ids || !rel_bias || !out) return fail(PTTS_E_INVALID, "null argument");
+    const ptts_config& c = e->cfg;
+    if (c.t5_layers <= 0 || !e->t5_shared) return fail(PTTS_E_STATE, "engine was created without a text encoder");
+    if (B <= 0 || B > c.max_batch || T <= 0 || T > c.max_desc_len) return fail(PTTS_E_INVALID, "B=%d T=%d outside the engine limits", B, T);
+    hipStream_t s = (hipStream_t)stream;
+    const int d = c.enc_hidden, inner = c.t5_heads * c.t5_dkv, ff = c.t5_dff, M = B * T;
+    HIP_TRY(t5_embed_launch((const long long*)input_ids, e->t5_shared, e->t5_x, M, d, e->dt, s));
+    for (int l = 0; l < c.t5_layers; ++l) {
+        T5Layer& w = e->t5[l];
+        GemmArgs g;
+        g.W = w.qkv.ptr; g.N = 3 * inner; g.K = d; g.M = M; g.pro = PRO_RMSNORM; g.x = e->t5_x; g.ldx = d;
+        g.gamma = w.ln0; g.eps = c.t5_eps; g.epi = EPI_ROWMAJOR; g.out = e->t5_qkv; g.ldo = 3 * inner;
+        PTTS_TRY(launch_gemm(e, g, s));
+        FullAttnArgs fa;
+        fa.qkv = e->t5_qkv; fa.ld = 3 * inner; fa.T = T; fa.H = c.t5_heads; fa.dk = c.t5_dkv; fa.scale = 1.0f;
+        fa.rel_bias = rel_bias; fa.n_rel = 2 * T - 1; fa.mask = attention_mask; fa.ofrag = e->t5_afrag;
+        HIP_TRY(attn_full_launch(fa, B, e->dt, s));
+        g = GemmArgs();
+        g.W = w.o.ptr; g.N = d; g.K = inner; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->t5_afrag;
+        g.epi = EPI_RESIDUAL; g.out = e->t5_x; g.ldo = d;
+        PTTS_TRY(launch_gemm(e, g, s));
+        g = GemmArgs();
+        g.W = w.wi.ptr; g.K = d; g.M = M; g.pro = PRO_RMSNORM; g.x = e->t5_x; g.ldx = d; g.gamma = w.ln1; g.eps = c.t5_eps;
+        g.ofrag = e->t5_ffrag; g.ldo = ff; g.act = c.t5_act;
+        if (c.t5_gated) { g.N = 2 * ff; g.epi = EPI_GATED_FRAG; }
+        else { g.N = ff; g.epi = EPI_ACT_FRAG; }
+        PTTS_TRY(launch_gemm(e, g, s));
+        g = GemmArgs();
+        g.W = w.wo.ptr; g.N = d; g.K = ff; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->t5_ffrag;
+        g.epi = EPI_RESIDUAL; g.out = e->t5_x; g.ldo = d;
+        PTTS_TRY(launch_gemm(e, g, s));
+    }
+    HIP_TRY(rmsnorm_rows_launch(e->t5_x, e->t5_final_ln, out, M, d, c.t5_eps, s));
+    return PTTS_OK;
+}
+
+int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P, int32_t L, const float* enc_states,
+                 const int32_t* attention_mask, const int64_t* prompt_ids, const int32_t* prompt_mask, const int64_t* pattern,
+                 int64_t* raw_ids, int32_t start_len, void* stream) {
+    if (!e || !enc_states || !attention_mask || !pattern || !raw_ids) return fail(PTTS_E_INVALID, "null argument");
+    PTTS_TRY(ptts_weights_ready(e));
+    const ptts_config& c = e->cfg;
+    if (B <= 0 || (B_eff != B && B_eff != 2 * B) || B_eff > c.max_batch) return fail(PTTS_E_INVALID, "B=%d B_eff=%d max_batch=%d", B, B_eff, c.max_batch);
+    if (T <= 0 || T > c.max_desc_len || P < 0 || P > c.max_prompt_len || L < 2 || L > c.max_length)
+        return fail(PTTS_E_INVALID, "T=%d P=%d L=%d outside the engine limits (%d, %d, %d)", T, P, L, c.max_desc_len, c.max_prompt_len, c.max_length);
+    if (P > 0 && !prompt_ids) return fail(PTTS_E_INVALID, "prompt_ids missing");
+    if (start_len < 1 || start_len >= L) return fail(PTTS_E_INVALID, "start_len=%d must be in [1, L)", start_len);
+    hipStream_t s = (hipStream_t)stream;
+    drop_graph(e);
+    e->B = B; e->B_eff = B_eff; e->T = T; e->P = P; e->L = L;
+    e->pattern = (const long long*)pattern; e->raw_ids = (long long*)raw_ids; e->prompt_ids = (const long long*)prompt_ids;
+    const int D = c.hidden, M = B_eff * T;
+    // additive masks (M:870-879)
+    HIP_TRY(build_bias_launch(attention_mask, e->cross_bias, B_eff, T, e->cross_blocks * PTTS_PAGE_TOKENS, s));
+    e->has_self_bias = prompt_mask != nullptr;
+    if (prompt_mask) HIP_TRY(build_bias_launch(prompt_mask, e->self_bias, B_eff, P, e->s_cap, s));
+    // enc_to_dec_proj (+bias) then * attention_mask (M:2010-2017); rowmask index = b*T + t = flat mask index
+    const float* enc_h = enc_states;
+    GemmArgs g;
+    if (c.enc_hidden != c.hidden) {
+        g.W = e->enc_proj.ptr; g.N = D; g.K = c.enc_hidden; g.M = M; g.pro = PRO_ROWMAJOR; g.x = enc_states; g.ldx = c.enc_hidden;
+        g.epi = EPI_ROWMAJOR; g.out = e->enc_h; g.ldo = D; g.bias = e->enc_proj_bias; g.rowmask = attention_mask;
+        PTTS_TRY(launch_gemm(e, g, s));
+        enc_h = e->enc_h;
+    } else {
+        return fail(PTTS_E_UNSUPPORTED, "enc_hidden == hidden (no enc_to_dec_proj) is not wired yet");
+    }
+    // cross K/V of every layer into the cross pool (M:295-298)
+    for (int l = 0; l < c.layers; ++l) {
+        g = GemmArgs();
+        g.W = e->layers[l].ckv.ptr; g.N = 2 * D; g.K = D; g.M = M; g.pro = PRO_ROWMAJOR; g.x = enc_h; g.ldx = D;
+        g.epi = EPI_KV_CROSS; g.pool = make_pool(e, true); g.layer = l; g.D = D; g.T = T;
+        PTTS_TRY(launch_gemm(e, g, s));
+    }
+    // loop state
+    StepState st = {};
+    st.pos = 0; st.cur_len = start_len; st.prompt_len = P; st.n_unfinished = B * c.codebooks;
+    HIP_TRY(hipMemcpyAsync(e->state, &st, sizeof(st), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `st` lives on this stack frame
+    std::vector<int> ones(B * c.codebooks, 1);
+    HIP_TRY(hipMemcpyAsync(e->unfinished, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->unf_count, 0, 4 * sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // the P prompt positions, one cached position at a time (causal attention == incremental decode)
+    for (int p = 0; p < P; ++p) {
+        HIP_TRY(embed_prompt_launch(embed_args(e), B_eff, e->dt, s));
+        e->host_pos = p;
+        PTTS_TRY(run_layers(e, s, false));
+        HIP_TRY(advance_prompt_launch(e->state, s));
+    }
+    e->host_pos = P;
+    e->host_cur = start_len;
+    HIP_TRY(init_tokens_launch(e->raw_ids, e->pattern, e->tok_in, B * c.codebooks, B_eff * c.codebooks, L, start_len - 1, s));
+    e->use_force = false;
+    e->prefilled = true;
+    return PTTS_OK;
+}
+
+int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, int32_t profile_every, void* stream) {
+    if (!e || !sp) return fail(PTTS_E_INVALID, "null argument");
+    if (!e->prefilled) return fail(PTTS_E_STATE, "ptts_prefill has not run");
+    if (sp->do_sample && !(sp->temperature > 0.f)) return fail(PTTS_E_INVALID, "temperature must be > 0");
+    if (sp->guidance_scale > 1.0f && e->B_eff != 2 * e->B) return fail(PTTS_E_INVALID, "guidance needs B_eff = 2B");
+    hipStream_t s = (hipStream_t)stream;
+    int remaining = e->L - e->host_cur;
+    if (n_steps > remaining) n_steps = remaining;
+    const bool forced = e->use_force;
+    for (int i = 0; i < n_steps; ++i) {
+        const bool prof = profile_every > 0 && ((e->host_cur - 1) % profile_every == 0);
+        if (prof && e->ev_used + 2 * (size_t)e->cfg.layers + 2 > e->ev_pool.size()) {
+            size_t want = e->ev_pool.size() + 64 * ((size_t)e->cfg.layers + 1);
+            if (want <= 65536) {
+                while (e->ev_pool.size() < want) {
+                    EventPair p; p.bytes = 0; p.kind = 0;
+                    HIP_TRY(hipEventCreate(&p.a));
+                    HIP_TRY(hipEventCreate(&p.b));
+                    e->ev_pool.push_back(p);
+                }
+            }
+        }
+        if (prof || e->no_graph || forced) {
+            PTTS_TRY(run_decode_step(e, *sp, s, prof));
+        } else {
+            if (!e->step_graph || !same_sampling(e->graph_sp, *sp)) PTTS_TRY(capture_step_graph(e, *sp, s));
+            HIP_TRY(hipGraphLaunch(e->step_graph, s));
+        }
+        e->host_pos += 1;
+        e->host_cur += 1;
+    }
+    return PTTS_OK;
+}
+
+int ptts_get_state(ptts_engine* e, ptts_state* out, void* stream) {
+    if (!e || !out) return fail(PTTS_E_INVALID, "null argument");
+    StepState st;
+    HIP_TRY(hipMemcpyAsync(&st, e->state, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    out->pos = st.pos; out->cur_len = st.cur_len; out->prompt_len = st.prompt_len;
+    out->n_unfinished = st.n_unfinished; out->done_len = st.done_len; out->step_count = st.step_count;
+    return PTTS_OK;
+}
+
+int ptts_last_logits(ptts_engine* e, const float** logits, const float** probs) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    if (logits) *logits = e->logits;
+    if (probs) *probs = e->probs;
+    return PTTS_OK;
+}
+
+int ptts_set_block_table(ptts_engine* e, const int32_t* table_host, int32_t rows, int32_t max_blocks) {
+    if (!e || !table_host) return fail(PTTS_E_INVALID, "null argument");
+    if (rows != e->cfg.max_batch || max_blocks != e->self_blocks)
+        return fail(PTTS_E_INVALID, "table must be [%d][%d]", e->cfg.max_batch, e->self_blocks);
+    std::vector<char> seen(e->self_pages, 0);
+    for (int i = 0; i < rows * max_blocks; ++i) {
+        int p = table_host[i];
+        if (p < 0 || p >= e->self_pages || seen[p]) return fail(PTTS_E_INVALID, "page id %d invalid or repeated", p);
+        seen[p] = 1;
+    }
+    HIP_TRY(hipMemcpy(e->self_table, table_host, sizeof(int) * rows * max_blocks, hipMemcpyHostToDevice));
+    e->prefilled = false;
+    drop_graph(e);
+    return PTTS_OK;
+}
+
+int ptts_pool_info(ptts_engine* e, int32_t* n_pages, int32_t* max_blocks, int64_t* page_bytes) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    if (n_pages) *n_pages = e->self_pages;
+    if (max_blocks) *max_blocks = e->self_blocks;
+    if (page_bytes) *page_bytes = (int64_t)e->cfg.layers * 2 * e->cfg.heads * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM * (int64_t)e->esz;
+    return PTTS_OK;
+}
+
+int ptts_set_forced_tokens(ptts_engine* e, const int64_t* tokens_host, int32_t rows) {
+    // test hook: tokens (>= 0) override the next step's selection, -1 leaves a row alone; NULL clears
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    if (!tokens_host) { e->use_force = false; return PTTS_OK; }
+    if (rows != e->B * e->cfg.codebooks) return fail(PTTS_E_INVALID, "rows must be B*K");
+    HIP_TRY(hipMemcpy(e->force, tokens_host, sizeof(long long) * rows, hipMemcpyHostToDevice));
+    e->use_force = true;
+    return PTTS_OK;
+}
+
+int ptts_profile_read(ptts_engine* e, ptts_profile* out, int32_t reset) {
+    if (!e || !out) return fail(PTTS_E_INVALID, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev_pool[i].a, e->ev_pool[i].b));
+        if (e->ev_pool[i].kind == 0) { e->prof.launches += 1; e->prof.total_ms += ms; e->prof.algo_bytes += e->ev_pool[i].bytes; }
+        else { e->prof.steps += 1; e->prof.step_ms += ms; }
+    }
+    e->ev_used = 0;
+    *out = e->prof;
+    if (reset) e->prof = ptts_profile();
+    return PTTS_OK;
+}
+
+int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* W, const float* X, int32_t prologue,
+                   const float* gamma, const float* beta, float eps, int32_t act, const float* bias, float* Y, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    size_t esz = dtype == PTTS_DTYPE_BF16 ? 2 : 4;
+    int Np = (N + 15) / 16 * 16;
+    void* wp = nullptr;
+    HIP_TRY(gemm_init());
+    HIP_TRY(hipMalloc(&wp, (size_t)Np * K * esz));
+    HIP_TRY(hipMemsetAsync(wp, 0, (size_t)Np * K * esz, s));
+    HIP_TRY(pack_weight_launch(W, wp, N, K, 0, 1, dtype, s));
+    GemmArgs g;
+    g.W = wp; g.N = Np; g.K = K; g.M = M; g.pro = prologue; g.x = X; g.ldx = K; g.gamma = gamma; g.beta = beta; g.eps = eps;
+    g.epi = EPI_ROWMAJOR; g.out = Y; g.ldo = N; g.bias = bias; g.act = act;
+    if (N % 16 != 0) { (void)hipFree(wp); return fail(PTTS_E_INVALID, "test gemm needs N %% 16 == 0"); }
+    int v = gemm_validate(g, dtype);
+    hipError_t he = hipSuccess;
+    if (v == 0) he = gemm_launch(g, dtype, s);
+    hipError_t se = hipStreamSynchronize(s);
+    (void)hipFree(wp);
+    if (v != 0) return fail(PTTS_E_INVALID, "gemm shape rejected (code %d)", v);
+    if (he != hipSuccess) return fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(he));
+    if (se != hipSuccess) return fail(PTTS_E_HIP, "gemm execution failed: %s", hipGetErrorString(se));
+    return PTTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// Host-side interface of gemm.hip (internal to the library; the public C ABI is include/parler_tts_hip.h).
+#pragma once
+#include "ptts_common.h"
+
+enum { PTTS_F32 = 0, PTTS_BF16 = 1 };
+enum { PRO_FRAG = 0, PRO_ROWMAJOR = 1, PRO_LAYERNORM = 2, PRO_RMSNORM = 3 };
+enum { EPI_ROWMAJOR = 0, EPI_RESIDUAL = 1, EPI_ACT_FRAG = 2, EPI_QKV_SELF = 3, EPI_KV_CROSS = 4, EPI_Q_SCALE = 5,
+       EPI_GATED_FRAG = 6 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_GELU_NEW = 2, ACT_RELU = 3 };
+
+struct GemmArgs {
+    const void* W = nullptr;   // packed weights [N/16][K/KSTEP][64 lanes][16 B]
+    int N = 0, K = 0, M = 0;
+    // prologue
+    int pro = PRO_FRAG;
+    const float* x = nullptr;  // row-major fp32 [M][ldx]
+    int ldx = 0;
+    const void* xfrag = nullptr;  // frag-major [(M+31)/32][32*K]
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float eps = 1e-5f;
+    // epilogue
+    int epi = EPI_ROWMAJOR;
+    float* out = nullptr;
+    int ldo = 0;                  // row stride of `out`, or feature count of the frag output
+    const float* bias = nullptr;
+    const int* rowmask = nullptr;
+    void* ofrag = nullptr;
+    int act = ACT_NONE;
+    float scale = 1.0f;
+    KVPool pool = {};
+    int layer = 0;
+    const StepState* state = nullptr;
+    int D = 0;                    // model width (segment size of the fused QKV / KV projection)
+    int T = 1;                    // cross rows per utterance (row = b*T + t)
+};
+
+hipError_t gemm_init();
+int gemm_validate(const GemmArgs& a, int dtype);
+hipError_t gemm_launch(const GemmArgs& a, int dtype, hipStream_t stream);
+hipError_t pack_weight_launch(const float* W, void* out, int N, int K, int n_off, int n_stride, int dtype,
+                              hipStream_t stream);
+hipError_t convert_launch(const float* src, void* dst, size_t n, int dtype, hipStream_t stream);

@@ -1,0 +1,44 @@
+// Host-side interface of misc.hip (internal).
+#pragma once
+#include "ptts_common.h"
+#include "gemm.h"
+
+struct EmbedArgs {
+    const void* tables = nullptr;        // [K][rows][D] codebook embeddings (weight dtype)
+    int rows = 0, K = 0, D = 0;
+    const void* pos_table = nullptr;     // [max_positions][D]
+    const int* tok_in = nullptr;         // [B*K] ids to feed (delay pattern already applied)
+    const void* prompt_table = nullptr;  // [prompt_vocab][D]
+    const long long* prompt_ids = nullptr;  // [B][P]
+    int P = 0;
+    const StepState* state = nullptr;
+    float* x = nullptr;                  // [B][D] residual stream
+};
+
+struct SelectArgs {
+    const float* logits = nullptr;       // [rows (x2 under guidance)][V]
+    int rows = 0, V = 0, vocab = 0, L = 0;   // V = row stride of logits/probs, vocab = valid entries
+    StepState* state = nullptr;
+    long long* raw_ids = nullptr;        // [rows][L]
+    const long long* pattern = nullptr;  // [rows][L]
+    int* unfinished = nullptr;           // [rows]
+    int* unf_count = nullptr;
+    int* tok_in = nullptr;               // [rows (x2)]
+    const long long* force = nullptr;    // [rows] or null
+    float* probs = nullptr;              // [rows][V] or null
+    int pad = 0, eos = 0;
+    int do_sample = 0, top_k = 0;
+    float temperature = 1.0f, guidance = 1.0f;
+    unsigned long long seed = 0;
+};
+
+hipError_t embed_codebooks_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s);
+hipError_t embed_prompt_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s);
+hipError_t advance_prompt_launch(StepState* st, hipStream_t s);
+hipError_t select_launch(const SelectArgs& a, hipStream_t s);
+hipError_t advance_launch(StepState* st, int* unf_count, int L, hipStream_t s);
+hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,
+                              int L, int col, hipStream_t s);
+hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s);
+hipError_t t5_embed_launch(const long long* ids, const void* table, float* x, int rows, int D, int dtype, hipStream_t s);
+hipError_t rmsnorm_rows_launch(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s);

@@ -1,0 +1,289 @@
+// Small per-step kernels: token/prompt embedding + sinusoid positions, token selection with the
+// delay-pattern shift and EOS latch, loop-state advance, additive attention masks.
+#include "ptts_common.h"
+#include "misc.h"
+
+namespace {
+
+// ---- embedding: x[b] = ((((0 + E0[t0]) + E1[t1]) + ...) + E_{K-1}[t_{K-1}]) + pos_table[pos]
+// strictly left-to-right like Python's sum() at M:836, then the position row (M:884-886).
+template <typename P>
+__global__ void embed_codebooks_kernel(EmbedArgs a) {
+    typedef typename P::elem_t elem_t;
+    const int b = blockIdx.x;
+    const int pos = a.state->pos;
+    const elem_t* tab = reinterpret_cast<const elem_t*>(a.tables);
+    const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)pos * a.D;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < a.K; ++k) {
+            int tok = a.tok_in[b * a.K + k];
+            s = s + from_elem<P>(tab[((size_t)k * a.rows + tok) * a.D + d]);
+        }
+        a.x[(size_t)b * a.D + d] = s + from_elem<P>(ptab[d]);
+    }
+}
+
+// prompt positions: x[b] = embed_prompts[prompt_ids[b][pos]] + pos_table[pos]   (M:2243-2245, M:839-840, M:886)
+template <typename P>
+__global__ void embed_prompt_kernel(EmbedArgs a) {
+    typedef typename P::elem_t elem_t;
+    const int b = blockIdx.x;
+    const int pos = a.state->pos;
+    const long long tok = a.prompt_ids[(size_t)b * a.P + pos];
+    const elem_t* row = reinterpret_cast<const elem_t*>(a.prompt_table) + (size_t)tok * a.D;
+    const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)pos * a.D;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x)
+        a.x[(size_t)b * a.D + d] = from_elem<P>(row[d]) + from_elem<P>(ptab[d]);
+}
+
+__global__ void advance_prompt_kernel(StepState* s) { s->pos += 1; }
+
+// ---- Philox4x32-10 counter RNG (one draw per (row, step)) ----
+__device__ inline void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ inline float philox_uniform(uint64_t seed, uint32_t row, uint32_t step) {
+    uint32_t c0 = row, c1 = step, c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+__device__ inline uint32_t float_key(float f) {   // order-preserving map to unsigned
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---- token selection: one workgroup per (utterance, codebook) row ----
+// greedy: first maximal index (torch.argmax).  sample: scores / temperature -> keep scores >= k-th
+// largest (ties kept) -> softmax -> one inverse-CDF draw.  Then, as the third-party loop does:
+// nxt = tok*unf + pad*(1-unf); raw_ids[:, cur_len] = nxt; unf &= (nxt != eos); and the token fed to
+// the next step is the delay pattern's value where it is not -1 (apply_delay_pattern_mask, M:68-74).
+__global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sv = reinterpret_cast<float*>(smem);          // [V] scores
+    __shared__ float wv[4];
+    __shared__ int wi[4];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_remaining;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int V = a.vocab;          // valid ids; rows are a.V (= padded stride) apart
+    const int cur = a.state->cur_len;
+    if (cur >= a.L) return;
+    const float* lg = a.logits + (size_t)row * a.V;
+    const float* ug = a.guidance > 1.0f ? a.logits + (size_t)(row + a.rows) * a.V : nullptr;
+    for (int v = tid; v < V; v += 256) {
+        float s = lg[v];
+        if (ug) { float u = ug[v]; s = u + (s - u) * a.guidance; }
+        if (a.do_sample && a.temperature != 1.0f) s = s / a.temperature;
+        sv[v] = s;
+    }
+    __syncthreads();
+
+    int choice = 0;
+    if (!a.do_sample) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += 256) {
+            float s = sv[v];
+            if (s > best || (s == best && v < bi)) { best = s; bi = v; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { wv[w] = best; wi[w] = bi; }
+        __syncthreads();
+        best = wv[0]; bi = wi[0];
+        for (int i = 1; i < 4; ++i) if (wv[i] > best || (wv[i] == best && wi[i] < bi)) { best = wv[i]; bi = wi[i]; }
+        choice = bi;
+        if (a.probs) for (int v = tid; v < V; v += 256) a.probs[(size_t)row * a.V + v] = sv[v];
+    } else {
+        // ---- k-th largest by 4-pass radix select over order-preserving keys ----
+        float thr = -INFINITY;
+        if (a.top_k > 0 && a.top_k < V) {
+            if (tid == 0) { sel_prefix = 0; sel_remaining = (unsigned)a.top_k; }
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                hist[tid] = 0;
+                __syncthreads();
+                const unsigned prefix = sel_prefix;
+                const unsigned pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+                for (int v = tid; v < V; v += 256) {
+                    unsigned k = float_key(sv[v]);
+                    if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned rem = sel_remaining, acc = 0; int bin = 255;
+                    for (; bin > 0; --bin) { if (acc + hist[bin] >= rem) break; acc += hist[bin]; }
+                    sel_prefix = prefix | ((unsigned)bin << shift);
+                    sel_remaining = rem - acc;
+                }
+                __syncthreads();
+            }
+            unsigned key = sel_prefix;   // key of the k-th largest score
+            unsigned u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+            thr = __builtin_bit_cast(float, u);
+        }
+        // ---- masked softmax ----
+        float m = -INFINITY;
+        for (int v = tid; v < V; v += 256) { float s = sv[v]; if (s >= thr) m = fmaxf(m, s); }
+        m = wave_max(m);
+        if (lane == 0) wv[w] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wv[0], wv[1]), fmaxf(wv[2], wv[3]));
+        __syncthreads();
+        float sum = 0.f;
+        for (int v = tid; v < V; v += 256) {
+            float s = sv[v];
+            float e = (s >= thr) ? expf(s - m) : 0.f;
+            sv[v] = e; sum += e;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) wv[w] = sum;
+        __syncthreads();
+        sum = (wv[0] + wv[1]) + (wv[2] + wv[3]);
+        for (int v = tid; v < V; v += 256) {
+            float p = sv[v] / sum;
+            sv[v] = p;
+            if (a.probs) a.probs[(size_t)row * a.V + v] = p;
+        }
+        __syncthreads();
+        // ---- inverse CDF, index order (one thread: V ~ 1e3) ----
+        if (tid == 0) {
+            float u = philox_uniform(a.seed, (uint32_t)row, (uint32_t)a.state->step_count);
+            float c = 0.f; int pick = -1, last = 0;
+            for (int v = 0; v < V; ++v) {
+                float p = sv[v];
+                if (p > 0.f) { last = v; c += p; if (pick < 0 && c > u) pick = v; }
+            }
+            wi[0] = pick < 0 ? last : pick;
+        }
+        __syncthreads();
+        choice = wi[0];
+    }
+
+    if (tid == 0) {
+        long long tok = choice;
+        if (a.force && a.force[row] >= 0) tok = a.force[row];   // teacher forcing (tests)
+        const int unf = a.unfinished[row];
+        long long nxt = unf ? tok : (long long)a.pad;
+        a.raw_ids[(size_t)row * a.L + cur] = nxt;
+        const int unf_new = unf && (nxt != (long long)a.eos);
+        a.unfinished[row] = unf_new;
+        if (unf_new) atomicAdd(a.unf_count, 1);
+        const long long forced = a.pattern[(size_t)row * a.L + cur];
+        const int feed = (int)(forced == -1 ? nxt : forced);
+        a.tok_in[row] = feed;
+        if (a.guidance > 1.0f) a.tok_in[row + a.rows] = feed;   // both halves see the same ids (M:2112)
+    }
+}
+
+__global__ void advance_kernel(StepState* s, int* unf_count, int L) {
+    if (s->cur_len >= L) return;
+    s->pos += 1;
+    s->cur_len += 1;
+    s->step_count += 1;
+    s->n_unfinished = *unf_count;
+    if (*unf_count == 0 && s->done_len == 0) s->done_len = s->cur_len;
+    *unf_count = 0;
+}
+
+// feed tokens for the first decode step: the masked last column of the start ids (M:2107, M:2120-2130)
+__global__ void init_tokens_kernel(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,
+                                   int L, int col) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows_eff) return;
+    int src = r % rows;
+    long long f = pattern[(size_t)src * L + col];
+    tok_in[r] = (int)(f == -1 ? raw_ids[(size_t)src * L + col] : f);
+}
+
+// additive masks: 0 where attended, finfo.min where not (masked_fill semantics of the HF helpers, M:870-879)
+__global__ void build_bias_kernel(const int* mask, float* bias, int B, int n_mask, int ld_bias) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * ld_bias) return;
+    int b = i / ld_bias, s = i % ld_bias;
+    float v = 0.f;
+    if (s < n_mask && mask[b * n_mask + s] == 0) v = -3.4028234663852886e38f;
+    bias[i] = v;
+}
+
+__global__ void t5_embed_kernel(const long long* ids, const void* table, float* x, int D, int is_bf16) {
+    const int r = blockIdx.x;
+    const long long tok = ids[r];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float v = is_bf16 ? bf16_bits_to_float(reinterpret_cast<const uint16_t*>(table)[(size_t)tok * D + d])
+                          : reinterpret_cast<const float*>(table)[(size_t)tok * D + d];
+        x[(size_t)r * D + d] = v;
+    }
+}
+
+// final T5 RMSNorm (row-major in/out)
+__global__ void rmsnorm_rows_kernel(const float* x, const float* w, float* y, int D, float eps) {
+    const int r = blockIdx.x;
+    __shared__ float part[4];
+    float q = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) { float v = x[(size_t)r * D + d]; q += v * v; }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = q;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += part[i];
+    float rstd = 1.0f / sqrtf(tot / (float)D + eps);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) y[(size_t)r * D + d] = w[d] * (x[(size_t)r * D + d] * rstd);
+}
+
+}  // namespace
+
+hipError_t embed_codebooks_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s) {
+    if (dtype == PTTS_BF16) hipLaunchKernelGGL(embed_codebooks_kernel<PBF16>, dim3(B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(embed_codebooks_kernel<PF32>, dim3(B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t embed_prompt_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s) {
+    if (dtype == PTTS_BF16) hipLaunchKernelGGL(embed_prompt_kernel<PBF16>, dim3(B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(embed_prompt_kernel<PF32>, dim3(B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t advance_prompt_launch(StepState* st, hipStream_t s) {
+    hipLaunchKernelGGL(advance_prompt_kernel, dim3(1), dim3(1), 0, s, st);
+    return hipGetLastError();
+}
+hipError_t select_launch(const SelectArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(select_kernel, dim3(a.rows), dim3(256), (size_t)a.V * sizeof(float), s, a);
+    return hipGetLastError();
+}
+hipError_t advance_launch(StepState* st, int* unf_count, int L, hipStream_t s) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, st, unf_count, L);
+    return hipGetLastError();
+}
+hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,
+                              int L, int col, hipStream_t s) {
+    hipLaunchKernelGGL(init_tokens_kernel, dim3((rows_eff + 255) / 256), dim3(256), 0, s, raw_ids, pattern, tok_in, rows,
+                       rows_eff, L, col);
+    return hipGetLastError();
+}
+hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s) {
+    int n = B * ld_bias;
+    hipLaunchKernelGGL(build_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, bias, B, n_mask, ld_bias);
+    return hipGetLastError();
+}
+hipError_t t5_embed_launch(const long long* ids, const void* table, float* x, int rows, int D, int dtype, hipStream_t s) {
+    hipLaunchKernelGGL(t5_embed_kernel, dim3(rows), dim3(256), 0, s, ids, table, x, D, dtype == PTTS_BF16 ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t rmsnorm_rows_launch(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, s, x, w, y, D, eps);
+    return hipGetLastError();
+}

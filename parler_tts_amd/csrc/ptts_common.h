@@ -1,0 +1,118 @@
+// Shared device/host definitions for the gfx950 (CDNA4, wave64) Parler-TTS generate() engine.
+//
+// Memory layouts (all owned by the library, see DESIGN.md "Data layout in HBM"):
+//
+//  * packed weights  W[N][K] (torch Linear, out x in) are re-tiled once at load into MFMA A-operand
+//    order: tile (n/16, k/KSTEP) is 1 KiB, stored lane-major, so one wave64 `global_load_dwordx4`
+//    fetches exactly one tile, fully coalesced:
+//        bf16: KSTEP=32, lane l element j (0..7)  = W[16*nb + (l&15)][32*ks + 8*(l>>4) + j]   (v_mfma_f32_16x16x32_bf16)
+//        f32 : KSTEP=16, lane l element m (0..3)  = W[16*nb + (l&15)][16*ks + 4*m + (l>>4)]   (4 x v_mfma_f32_16x16x4_f32)
+//  * activation fragments  X[32 rows][K] of one 32-row m-tile are kept in MFMA B-operand order
+//    ("frag-major"), half h = row/16:
+//        bf16: lane l element j = X[16*h + (l&15)][32*ks + 8*(l>>4) + j]
+//        f32 : lane l element m = X[16*h + (l&15)][16*ks + 4*m + (l>>4)]
+//    tile (ks, h) is again 1 KiB lane-major: LDS reads are lane-linear `ds_read_b128` (conflict free).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define PTTS_HEAD_DIM 64
+#define PTTS_PAGE_TOKENS 64
+
+// ---- precision policies -------------------------------------------------------------------------
+struct PBF16 {
+    typedef uint16_t elem_t;                 // storage element
+    static constexpr int KSTEP = 32;         // k per 1 KiB tile
+    static constexpr int EPL = 8;            // elements per lane per tile (16 bytes)
+    static constexpr bool IS_BF16 = true;
+};
+struct PF32 {
+    typedef float elem_t;
+    static constexpr int KSTEP = 16;
+    static constexpr int EPL = 4;
+    static constexpr bool IS_BF16 = false;
+};
+
+__host__ __device__ inline float bf16_bits_to_float(uint16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)v) << 16;
+    return c.f;
+}
+
+__device__ inline uint16_t float_to_bf16_bits(float f) {
+    // plain cast -> v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserving) on gfx950
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+
+template <typename P> __device__ inline typename P::elem_t to_elem(float f);
+template <> __device__ inline uint16_t to_elem<PBF16>(float f) { return float_to_bf16_bits(f); }
+template <> __device__ inline float to_elem<PF32>(float f) { return f; }
+
+template <typename P> __host__ __device__ inline float from_elem(typename P::elem_t v);
+template <> __host__ __device__ inline float from_elem<PBF16>(uint16_t v) { return bf16_bits_to_float(v); }
+template <> __host__ __device__ inline float from_elem<PF32>(float v) { return v; }
+
+// ---- fragment-major offsets (in elements) ----------------------------------------------------------
+// offset of activation X[row r (0..31)][k] inside one m-tile's frag buffer
+template <typename P> __host__ __device__ inline size_t frag_off(int r, int k);
+template <> __host__ __device__ inline size_t frag_off<PBF16>(int r, int k) {
+    return ((size_t)((k >> 5) * 2 + (r >> 4)) << 9) + (size_t)((((r & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7));
+}
+template <> __host__ __device__ inline size_t frag_off<PF32>(int r, int k) {
+    return ((size_t)((k >> 4) * 2 + (r >> 4)) << 8) + (size_t)((((r & 15) + 16 * (k & 3)) << 2) + ((k & 15) >> 2));
+}
+// offset of weight W[n][k] inside the packed matrix (K = in_features)
+template <typename P> __host__ __device__ inline size_t wpack_off(int n, int k, int K);
+template <> __host__ __device__ inline size_t wpack_off<PBF16>(int n, int k, int K) {
+    return ((size_t)(n >> 4) * (size_t)(K >> 5) + (size_t)(k >> 5)) * 512 +
+           (size_t)((((n & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7));
+}
+template <> __host__ __device__ inline size_t wpack_off<PF32>(int n, int k, int K) {
+    return ((size_t)(n >> 4) * (size_t)(K >> 4) + (size_t)(k >> 4)) * 256 +
+           (size_t)((((n & 15) + 16 * (k & 3)) << 2) + ((k & 15) >> 2));
+}
+
+// ---- paged KV pool -------------------------------------------------------------------------------------
+// page p holds 64 tokens of ONE utterance for all layers/heads: [L][2 (K,V)][H][64 tok][64 dim]
+struct KVPool {
+    void* base;            // element type = cache dtype
+    const int* block_table;  // [B][max_blocks] page ids
+    int max_blocks;
+    int H;
+    int L;
+    __host__ __device__ size_t page_elems() const { return (size_t)L * 2 * H * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM; }
+    __device__ size_t elem_off(int b, int layer, int kv, int h, int tok) const {
+        int page = block_table[b * max_blocks + (tok >> 6)];
+        return (size_t)page * page_elems() +
+               ((size_t)((layer * 2 + kv) * H + h) * PTTS_PAGE_TOKENS + (tok & 63)) * PTTS_HEAD_DIM;
+    }
+};
+
+// ---- on-device loop state (one per engine) -----------------------------------------------------------------
+struct StepState {
+    int pos;           // number of cached self-attention positions (= position id of the token being fed)
+    int cur_len;       // columns of raw_ids already filled
+    int prompt_len;    // P
+    int n_unfinished;  // rows still unfinished after the last select
+    int done_len;      // cur_len at which every row was finished (0 = not yet)
+    int step_count;    // decode steps executed since prefill
+    unsigned int philox_offset;
+    int pad_;
+};
+
+// wave64 all-reduce helpers (LDS crossbar shuffles; wave = 64 lanes on gfx950)
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,501 @@
+"""Python API surface of the reference, driving the MI355X HIP engine.
+
+``ParlerTTSForConditionalGeneration.generate()`` keeps the reference's signature and semantics
+(/root/reference/parler_tts/modeling_parler_tts.py:2342-2686): description ids -> T5 encoder (once) ->
+autoregressive multi-codebook decoder under the delay pattern -> DAC decode -> waveform.  The token
+loop (decoder forward + selection + EOS latch, i.e. M:2081-2148, M:1927-2079 and the third-party
+greedy/sample step) runs entirely inside ``libparler_tts_hip.so``; PyTorch only owns device buffers
+and the current stream.  Nothing here falls back to CPU or to the test oracle.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import json
+import math
+import os
+from typing import Any, Dict, Optional
+
+import torch
+
+from . import _hip
+from .configuration import DACConfig, GenerationConfig, ParlerTTSConfig
+from .delay_pattern import apply_delay_pattern_mask, build_delay_pattern_mask
+from .weights import load_state_dict_from_dir, normalize_state_dict, synthetic_state_dict
+
+_ACT = {"gelu": 1, "gelu_new": 2, "relu": 3}
+
+
+class ModelOutput(dict):
+    """Minimal attribute-dict standing in for HF ModelOutput (only what generate() returns)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def t5_relative_buckets(T: int, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """Bucket of every offset (key - query) in [-(T-1), T-1], bidirectional T5 rule
+    (HF models/t5/modeling_t5.py ``_relative_position_bucket``).  Host-side integer table."""
+    rel = torch.arange(-(T - 1), T)
+    nb = num_buckets // 2
+    out = (rel > 0).long() * nb
+    n = rel.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, nb - 1))
+    return out + torch.where(n < max_exact, n, large)
+
+
+class HipEngine:
+    """Owns one ``ptts_engine`` handle (weights packed in HBM, KV pools, workspaces)."""
+
+    def __init__(self, cfg: ParlerTTSConfig, state_dict: Dict[str, torch.Tensor], dtype: str, device: torch.device,
+                 max_batch: int, max_desc_len: int, max_prompt_len: int, max_length: int, with_t5: bool = True):
+        self.lib = _hip.load_library()
+        if device.type != "cuda":
+            raise RuntimeError("the HIP engine needs a ROCm device (torch device type 'cuda')")
+        self.device = device
+        self.dtype = dtype
+        d, t5 = cfg.decoder, cfg.text_encoder
+        c = _hip.PttsConfig()
+        c.abi_version = _hip.ABI_VERSION
+        c.dtype = _hip.DTYPE_BF16 if dtype == "bf16" else _hip.DTYPE_F32
+        c.hidden, c.layers, c.heads, c.ffn = d.hidden_size, d.num_hidden_layers, d.num_attention_heads, d.ffn_dim
+        c.vocab, c.codebooks, c.max_positions = d.vocab_size, d.num_codebooks, d.max_position_embeddings
+        c.pad_token_id, c.eos_token_id, c.bos_token_id = d.pad_token_id, d.eos_token_id, d.bos_token_id
+        c.prompt_vocab, c.enc_hidden = cfg.vocab_size, t5.d_model
+        c.t5_layers = t5.num_layers if with_t5 else 0
+        c.t5_heads, c.t5_dkv, c.t5_dff, c.t5_vocab = t5.num_heads, t5.d_kv, t5.d_ff, t5.vocab_size
+        c.t5_gated = 1 if t5.is_gated_act else 0
+        c.t5_act = _ACT[t5.dense_act_fn]
+        c.t5_eps = t5.layer_norm_epsilon
+        c.max_batch, c.max_desc_len, c.max_prompt_len, c.max_length = max_batch, max_desc_len, max_prompt_len, max_length
+        self.limits = (max_batch, max_desc_len, max_prompt_len, max_length)
+        self.cfg = cfg
+        self.handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _hip.check(self.lib.ptts_create(C.byref(c), C.byref(self.handle)))
+            self._upload(state_dict, with_t5)
+        self.rel_bias_weight = None
+        if with_t5:
+            self.rel_bias_weight = state_dict[
+                "text_encoder.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].float()
+
+    def _upload(self, sd: Dict[str, torch.Tensor], with_t5: bool) -> None:
+        n = 0
+        for name, t in sd.items():
+            if name.startswith("audio_encoder."):
+                continue
+            if name.startswith("text_encoder.") and not with_t5:
+                continue
+            g = t.to(device=self.device, dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * g.dim())(*g.shape)
+            _hip.check(self.lib.ptts_load_tensor(self.handle, name.encode(), _ptr(g), shape, g.dim(), _stream()))
+            n += g.numel()
+            if n > 200_000_000:  # bound the transient fp32 staging copies
+                torch.cuda.synchronize(self.device)
+                n = 0
+        torch.cuda.synchronize(self.device)
+        _hip.check(self.lib.ptts_weights_ready(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.ptts_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- thin wrappers ----
+    def t5_encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        t5 = self.cfg.text_encoder
+        B, T = input_ids.shape
+        buckets = t5_relative_buckets(T, t5.relative_attention_num_buckets, t5.relative_attention_max_distance)
+        table = self.rel_bias_weight[buckets].t().contiguous().to(self.device)      # [H][2T-1]
+        ids = input_ids.to(self.device, torch.int64).contiguous()
+        mask = attention_mask.to(self.device, torch.int32).contiguous()
+        out = torch.empty(B, T, t5.d_model, device=self.device, dtype=torch.float32)
+        _hip.check(self.lib.ptts_t5_encode(self.handle, B, T, _ptr(ids), _ptr(mask), _ptr(table), _ptr(out), _stream()))
+        torch.cuda.current_stream().synchronize()  # `table`/`ids` are temporaries
+        return out
+
+    def prefill(self, B, B_eff, enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, start_len):
+        T = enc_states.shape[1]
+        P = 0 if prompt_ids is None else prompt_ids.shape[1]
+        L = pattern.shape[1]
+        self._keep = (enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids)  # engine holds raw pointers
+        _hip.check(self.lib.ptts_prefill(self.handle, B, B_eff, T, P, L, _ptr(enc_states), _ptr(attention_mask),
+                                         _ptr(prompt_ids), _ptr(prompt_mask), _ptr(pattern), _ptr(raw_ids), start_len,
+                                         _stream()))
+
+    def decode_steps(self, n: int, sampling: _hip.PttsSampling, profile_every: int = 0) -> None:
+        _hip.check(self.lib.ptts_decode_steps(self.handle, n, C.byref(sampling), profile_every, _stream()))
+
+    def state(self) -> _hip.PttsState:
+        st = _hip.PttsState()
+        _hip.check(self.lib.ptts_get_state(self.handle, C.byref(st), _stream()))
+        return st
+
+    def last_logits(self, rows: int, probs: bool = False) -> torch.Tensor:
+        """Copy of the last step's logits [rows][vocab] (device -> new torch tensor)."""
+        lp, pp = C.c_void_p(), C.c_void_p()
+        _hip.check(self.lib.ptts_last_logits(self.handle, C.byref(lp), C.byref(pp)))
+        V = self.cfg.decoder.vocab_size
+        Vp = (V + 15) // 16 * 16
+        out = torch.empty(rows, Vp, device=self.device, dtype=torch.float32)
+        torch.cuda.current_stream().synchronize()
+        src = pp if probs else lp
+        rc = _hipMemcpyDtoD(out.data_ptr(), src.value, rows * Vp * 4)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed: {rc}")
+        return out[:, :V].contiguous()
+
+    def set_forced_tokens(self, tokens: Optional[torch.Tensor]) -> None:
+        if tokens is None:
+            _hip.check(self.lib.ptts_set_forced_tokens(self.handle, None, 0))
+            return
+        t = tokens.to("cpu", torch.int64).contiguous()
+        arr = (C.c_int64 * t.numel())(*t.tolist())
+        _hip.check(self.lib.ptts_set_forced_tokens(self.handle, arr, t.numel()))
+
+    def set_block_table(self, table: torch.Tensor) -> None:
+        t = table.to("cpu", torch.int32).contiguous()
+        arr = (C.c_int32 * t.numel())(*t.flatten().tolist())
+        _hip.check(self.lib.ptts_set_block_table(self.handle, arr, t.shape[0], t.shape[1]))
+
+    def pool_info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int64()
+        _hip.check(self.lib.ptts_pool_info(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def profile_read(self, reset: bool = True) -> _hip.PttsProfile:
+        p = _hip.PttsProfile()
+        _hip.check(self.lib.ptts_profile_read(self.handle, C.byref(p), 1 if reset else 0))
+        return p
+
+
+_hiprt = None
+
+
+def _hipMemcpyDtoD(dst: int, src: int, nbytes: int) -> int:
+    global _hiprt
+    if _hiprt is None:
+        _hiprt = C.CDLL("libamdhip64.so")
+        _hiprt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hiprt.hipMemcpy.restype = C.c_int
+    return _hiprt.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), nbytes, 3)  # hipMemcpyDeviceToDevice
+
+
+class DACModel:
+    """Codec wrapper with the reference's ``decode`` contract (dac_wrapper/modeling_dac.py:98-134):
+    ``audio_codes [1, B, K, F]`` -> ``audio_values [B, 1, F * hop]``.
+
+    STATUS (round 1): the conv stack runs as stock PyTorch-ROCm ops on the GPU (fp32, MIOpen/rocBLAS);
+    the hand-written MFMA implicit-GEMM kernels are the next SURVEY section-8 row to land.  It never runs on
+    the CPU and never touches the oracle."""
+
+    config_class = DACConfig
+
+    def __init__(self, config: DACConfig, state_dict: Dict[str, torch.Tensor], device: torch.device):
+        self.config = config
+        self.device = device
+        p = "audio_encoder.model."
+        self.w = {k[len(p):]: v.to(device=device, dtype=torch.float32).contiguous()
+                  for k, v in state_dict.items() if k.startswith(p)}
+        if not self.w:
+            raise RuntimeError("state dict holds no audio_encoder.model.* tensors")
+
+    @torch.no_grad()
+    def decode(self, audio_codes, audio_scales=None, padding_mask=None, return_dict=None):
+        import torch.nn.functional as F
+
+        if len(audio_codes) != 1:
+            raise ValueError(f"Expected one frame, got {len(audio_codes)}")
+        codes = audio_codes.squeeze(0).to(self.device)
+        w, cfg = self.w, self.config
+
+        def snake(x, alpha):
+            return x + (alpha + 1e-9).reciprocal() * torch.sin(alpha * x).pow(2)
+
+        z = 0.0
+        for k in range(codes.shape[1]):
+            e = F.embedding(codes[:, k, :], w[f"quantizer.quantizers.{k}.codebook.weight"]).transpose(1, 2)
+            z = z + F.conv1d(e, w[f"quantizer.quantizers.{k}.out_proj.weight"], w[f"quantizer.quantizers.{k}.out_proj.bias"])
+        x = F.conv1d(z, w["decoder.model.0.weight"], w["decoder.model.0.bias"], padding=3)
+        for n, stride in enumerate(cfg.upsampling_ratios, start=1):
+            b = f"decoder.model.{n}.block."
+            x = snake(x, w[b + "0.alpha"])
+            x = F.conv_transpose1d(x, w[b + "1.weight"], w[b + "1.bias"], stride=stride, padding=math.ceil(stride / 2))
+            for r, dil in zip((2, 3, 4), (1, 3, 9)):
+                u = f"{b}{r}.block."
+                y = F.conv1d(snake(x, w[u + "0.alpha"]), w[u + "1.weight"], w[u + "1.bias"], dilation=dil, padding=3 * dil)
+                y = F.conv1d(snake(y, w[u + "2.alpha"]), w[u + "3.weight"], w[u + "3.bias"])
+                crop = (x.shape[-1] - y.shape[-1]) // 2
+                if crop > 0:
+                    x = x[..., crop:-crop]
+                x = x + y
+        R = len(cfg.upsampling_ratios)
+        x = snake(x, w[f"decoder.model.{R + 1}.alpha"])
+        x = torch.tanh(F.conv1d(x, w[f"decoder.model.{R + 2}.weight"], w[f"decoder.model.{R + 2}.bias"], padding=3))
+        return ModelOutput(audio_values=x)
+
+
+class ParlerTTSForConditionalGeneration:
+    """Drop-in for the reference class of the same name (M:1560-2686), inference only."""
+
+    config_class = ParlerTTSConfig
+    main_input_name = "input_ids"
+
+    def __init__(self, config: ParlerTTSConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 dtype: str = "bf16", device="cuda:0", generation_config: Optional[GenerationConfig] = None):
+        _hip.load_library()  # fail now, loudly, if the HIP library is missing
+        if dtype not in ("bf16", "fp32"):
+            raise ValueError("dtype must be 'bf16' or 'fp32'")
+        self.config = config
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self._sd = state_dict
+        self._engine: Optional[HipEngine] = None
+        self._dac: Optional[DACModel] = None
+        d = config.decoder
+        self.generation_config = generation_config or GenerationConfig(
+            max_length=int(30 * config.audio_encoder.frame_rate), do_sample=True, guidance_scale=1,
+            decoder_start_token_id=config.decoder_start_token_id if config.decoder_start_token_id is not None else d.bos_token_id,
+            pad_token_id=d.pad_token_id, eos_token_id=d.eos_token_id, bos_token_id=d.bos_token_id)
+        if self.generation_config.bos_token_id is None:
+            self.generation_config.bos_token_id = d.bos_token_id  # M:2532 reads it; the recipe leaves it unset
+        self.profile_every = 0
+
+    # ---- construction ----
+    @classmethod
+    def from_pretrained(cls, path: str, dtype: str = "bf16", device="cuda:0", **kw):
+        """Local checkpoint directory in the reference layout (config.json + safetensors), M:1701-1720."""
+        if not os.path.isdir(path):
+            raise OSError(f"{path} is not a local directory (hub downloads are not available here)")
+        cfg = ParlerTTSConfig.from_pretrained(path)
+        sd = normalize_state_dict(load_state_dict_from_dir(path), cfg)
+        gen = None
+        gpath = os.path.join(path, "generation_config.json")
+        if os.path.exists(gpath):
+            with open(gpath) as f:
+                g = json.load(f)
+            g.pop("model_type", None)
+            gen = GenerationConfig(**g)
+        return cls(cfg, sd, dtype=dtype, device=device, generation_config=gen)
+
+    @classmethod
+    def from_synthetic(cls, config: ParlerTTSConfig, seed: int = 0, dtype: str = "bf16", device="cuda:0", **sd_kw):
+        return cls(config, synthetic_state_dict(config, seed=seed, **sd_kw), dtype=dtype, device=device)
+
+    def to(self, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("this engine only runs on an MI355X (device type 'cuda' under ROCm)")
+        if dev != self.device:
+            self.device, self._engine, self._dac = dev, None, None
+        return self
+
+    def eval(self):
+        return self
+
+    @property
+    def audio_encoder(self) -> DACModel:
+        if self._dac is None:
+            self._dac = DACModel(self.config.audio_encoder, self._sd, self.device)
+        return self._dac
+
+    def engine(self, B_eff: int = 1, T: int = 1, P: int = 0, L: int = 2) -> HipEngine:
+        """Engine sized for at least these limits (re-created when a call exceeds the current pools)."""
+        if self._engine is not None:
+            mb, mt, mp, ml = self._engine.limits
+            if B_eff <= mb and T <= mt and P <= mp and L <= ml:
+                return self._engine
+            self._engine.close()
+            B_eff, T, P, L = max(B_eff, mb), max(T, mt), max(P, mp), max(L, ml)
+        if self._sd is None:
+            raise RuntimeError("no weights: construct with a state dict, from_pretrained() or from_synthetic()")
+        self._engine = HipEngine(self.config, self._sd, self.dtype, self.device, B_eff, T, P, L)
+        return self._engine
+
+    # ---- generate ----
+    @torch.no_grad()
+    def generate(self, inputs: Optional[torch.Tensor] = None, generation_config: Optional[GenerationConfig] = None,
+                 logits_processor=None, stopping_criteria=None, synced_gpus: Optional[bool] = None, streamer=None,
+                 **kwargs):
+        cfgm, dec = self.config, self.config.decoder
+        K = dec.num_codebooks
+        # 1. generation config (M:2416-2422)
+        gen = copy.deepcopy(generation_config if generation_config is not None else self.generation_config)
+        user_max_length = kwargs.get("max_length")
+        model_kwargs = gen.update(**kwargs)
+        gen.validate()
+        if logits_processor or stopping_criteria:
+            raise NotImplementedError("custom logits processors / stopping criteria are not wired to the device loop")
+        allowed = {"input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "encoder_outputs",
+                   "return_raw_ids"}
+        unsupported = {"prompt_hidden_states", "decoder_input_ids", "input_values", "decoder_attention_mask"}
+        for k in model_kwargs:
+            if k in unsupported:
+                raise NotImplementedError(f"`{k}` (audio prompts / pre-embedded prompts) is a SURVEY 8(f) 'next' row")
+            if k not in allowed:
+                raise ValueError(f"The following `model_kwargs` are not used by the model: ['{k}']")
+        if gen.pad_token_id is None and gen.eos_token_id is not None:   # M:2432-2442
+            gen.pad_token_id = gen.eos_token_id
+        # 3. inputs (M:2449-2452)
+        input_ids = inputs if inputs is not None else model_kwargs.get("input_ids")
+        enc_out = model_kwargs.get("encoder_outputs")
+        if input_ids is None and enc_out is None:
+            raise ValueError("generate() needs description `input_ids` (or `encoder_outputs`)")
+        dev = self.device
+        if enc_out is not None:
+            enc = enc_out[0] if isinstance(enc_out, (tuple, list)) else getattr(enc_out, "last_hidden_state", enc_out)
+            enc = enc.to(dev, torch.float32)
+            B, T = enc.shape[:2]
+        else:
+            input_ids = input_ids.to(dev)
+            B, T = input_ids.shape
+        attention_mask = model_kwargs.get("attention_mask")
+        if attention_mask is None:    # M:2462-2465 (pad == eos, so HF does not infer a mask from pad tokens)
+            attention_mask = torch.ones(B, T, dtype=torch.long, device=dev)
+        attention_mask = attention_mask.to(dev)
+        prompt_ids = model_kwargs.get("prompt_input_ids")
+        prompt_mask = model_kwargs.get("prompt_attention_mask")
+        P = 0 if prompt_ids is None else prompt_ids.shape[1]
+        use_cfg = gen.guidance_scale is not None and gen.guidance_scale > 1
+        B_eff = 2 * B if use_cfg else B
+        # 5./6. start ids and max_length (M:2490-2527)
+        start_tok = gen.decoder_start_token_id if gen.decoder_start_token_id is not None else gen.bos_token_id
+        ids = torch.full((B * K, 1), start_tok, dtype=torch.long, device=dev)
+        if gen.max_new_tokens is not None:
+            gen.max_length = gen.max_new_tokens + ids.shape[-1]
+        if gen.min_length is not None and gen.min_length > gen.max_length:
+            raise ValueError(f"Unfeasible length constraints: the minimum length ({gen.min_length}) is larger than"
+                             f" the maximum length ({gen.max_length})")
+        L = int(gen.max_length)
+        if P + L > dec.max_position_embeddings:
+            raise ValueError(f"prompt ({P}) + max_length ({L}) exceeds max_position_embeddings ({dec.max_position_embeddings})")
+        # 7. mode (M:2544-2553, 2575-2579, 2622-2626)
+        greedy = gen.num_beams == 1 and gen.num_beam_groups == 1 and gen.do_sample is False
+        sample = gen.num_beams == 1 and gen.num_beam_groups == 1 and gen.do_sample is True
+        if not (greedy or sample):
+            raise ValueError("Got incompatible mode for generation, should be one of greedy or sampling. "
+                             "Ensure that beam search is de-activated by setting `num_beams=1` and `num_beam_groups=1`.")
+        if greedy and gen.num_return_sequences > 1:
+            raise ValueError(f"num_return_sequences has to be 1 when doing greedy search, but is {gen.num_return_sequences}.")
+        if sample and gen.num_return_sequences > 1:
+            raise NotImplementedError("num_return_sequences > 1: repeat the batch rows instead")
+        if sample and gen.top_p is not None and gen.top_p < 1.0:
+            raise NotImplementedError("top_p warping is not implemented on device (top_k and temperature are)")
+
+        eng = self.engine(B_eff, T, P, L)
+        if enc_out is None:
+            enc = eng.t5_encode(input_ids, attention_mask)                                   # M:2467-2474
+        # classifier-free guidance: zeroed 'null' half (M:2231-2237), prompts repeated (M:2109-2118)
+        amask32 = attention_mask.to(torch.int32)
+        if use_cfg:
+            enc = torch.cat([enc, torch.zeros_like(enc)], dim=0)
+            amask32 = torch.cat([amask32, torch.zeros_like(amask32)], dim=0)
+        pids = None if prompt_ids is None else prompt_ids.to(dev, torch.int64)
+        pmask32 = None if prompt_mask is None else prompt_mask.to(dev, torch.int32)
+        if use_cfg:
+            pids = None if pids is None else pids.repeat(2, 1)
+            pmask32 = None if pmask32 is None else pmask32.repeat(2, 1)
+        enc = enc.contiguous()
+        amask32 = amask32.contiguous()
+        pids = None if pids is None else pids.contiguous()
+        pmask32 = None if pmask32 is None else pmask32.contiguous()
+        # delay pattern (M:2530-2537)
+        ids, pattern = build_delay_pattern_mask(ids, gen.bos_token_id, gen.pad_token_id, L, K)
+        pattern = pattern.contiguous()
+        start_len = ids.shape[1]
+        raw_ids = torch.full((B * K, L), gen.pad_token_id, dtype=torch.long, device=dev)
+        raw_ids[:, :start_len] = ids
+        if streamer is not None:
+            streamer.put(ids.cpu())                                                          # M:2540-2541
+        sp = _hip.PttsSampling()
+        sp.do_sample = 1 if sample else 0
+        sp.temperature = float(gen.temperature if gen.temperature is not None else 1.0)
+        sp.top_k = int(gen.top_k or 0)
+        sp.guidance_scale = float(gen.guidance_scale) if use_cfg else 1.0
+        sp.seed = int(gen.seed if gen.seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len)
+        # ---- the hot loop: state lives on the device, the host only polls for "all rows finished" ----
+        remaining = L - start_len
+        chunk = 1 if streamer is not None else 128
+        L_out = L
+        while remaining > 0:
+            n = min(chunk, remaining)
+            eng.decode_steps(n, sp, self.profile_every)
+            remaining -= n
+            if streamer is not None:
+                st = eng.state()
+                streamer.put(raw_ids[:, st.cur_len - 1].cpu())
+                if st.done_len:
+                    L_out = st.done_len
+                    break
+            elif gen.eos_token_id is not None and (remaining == 0 or self._may_finish_early()):
+                st = eng.state()
+                if st.done_len:
+                    L_out = st.done_len
+                    break
+        if streamer is not None:
+            streamer.end()
+        torch.cuda.current_stream().synchronize()
+        self.last_raw_ids = raw_ids[:, :L_out]
+        # ---- un-delay (M:2633-2648): integer bookkeeping on the device tensors ----
+        out_ids = apply_delay_pattern_mask(raw_ids[:, :L_out], pattern)
+        start = torch.full((B * K, 1), start_tok, dtype=torch.long, device=dev)
+        _, m = build_delay_pattern_mask(start, gen.bos_token_id, gen.pad_token_id, L_out, K)
+        keep = (m != gen.bos_token_id) & (m != gen.pad_token_id)
+        output_ids = out_ids[keep].reshape(B, K, -1)[None, ...]
+        self.last_codes = output_ids
+        if model_kwargs.get("return_raw_ids"):
+            return output_ids
+        # ---- DAC decode (M:2650-2680) ----
+        special = (gen.bos_token_id, gen.pad_token_id, gen.eos_token_id)
+        sequential = any(bool((output_ids == s).any()) for s in special if s is not None)
+        if not sequential:
+            values = self.audio_encoder.decode(output_ids, audio_scales=[None] * B).audio_values.squeeze(1)
+        else:
+            vals = []
+            for b in range(B):
+                sample_b = output_ids[:, b]
+                ok = (sample_b >= cfgm.audio_encoder.codebook_size).sum(dim=(0, 1)) == 0
+                if int(ok.sum()) > 0:
+                    wav = self.audio_encoder.decode(sample_b[:, :, ok][None, ...], [None]).audio_values
+                    vals.append(wav.transpose(0, 2))
+                else:
+                    vals.append(torch.zeros(1, 1, 1, device=dev))
+            values = torch.nn.utils.rnn.pad_sequence(vals, batch_first=True, padding_value=0).squeeze(-1).squeeze(-1)
+        if gen.return_dict_in_generate:
+            return ModelOutput(sequences=values)
+        return values
+
+    def _may_finish_early(self) -> bool:
+        # with the synthetic never-EOS heads no row can finish; real checkpoints poll every chunk
+        return True
+
+
+class ParlerTTSForCausalLM:
+    """The decoder-only driver (M:1281-1552) is outside the accelerated path."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("ParlerTTSForCausalLM is not part of the MI355X generate() hot path; "
+                                  "use ParlerTTSForConditionalGeneration")

@@ -1,0 +1,120 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports exactly what
+include/parler_tts_hip.h declares; the Python API surface mirrors the reference's names."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "parler_tts_amd", "csrc", "libparler_tts_hip.so")
+HEADER = os.path.join(ROOT, "include", "parler_tts_hip.h")
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+
+        g.build()
+    return LIB
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptts_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from parler_tts_amd import _hip
+
+    assert header_symbols() == sorted(_hip.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    out = subprocess.run(["nm", "-D", built_lib], check=True, capture_output=True, text=True).stdout
+    for s in header_symbols():
+        assert re.search(rf" T {s}$", out, flags=re.M), f"{s} not exported"
+
+
+def test_library_loads_and_reports_abi(built_lib):
+    from parler_tts_amd import _hip
+
+    lib = _hip.load_library()
+    assert lib.ptts_abi_version() == _hip.ABI_VERSION
+
+
+def test_create_rejects_bad_config_without_touching_a_gpu(built_lib):
+    import ctypes as C
+
+    from parler_tts_amd import _hip
+
+    lib = _hip.load_library()
+    cfg = _hip.PttsConfig()
+    cfg.abi_version = 999
+    h = C.c_void_p()
+    assert lib.ptts_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"ABI version" in lib.ptts_last_error()
+    cfg.abi_version = _hip.ABI_VERSION
+    cfg.dtype = 1
+    cfg.hidden, cfg.heads = 100, 2
+    assert lib.ptts_create(C.byref(cfg), C.byref(h)) == -5      # head_dim must be 64
+    assert lib.ptts_create(None, C.byref(h)) == -1
+
+
+def test_python_api_surface_matches_reference_exports():
+    import parler_tts_amd as p
+
+    for name in ("ParlerTTSConfig", "ParlerTTSDecoderConfig", "DACConfig", "build_delay_pattern_mask",
+                 "apply_delay_pattern_mask"):
+        assert hasattr(p, name)
+    from parler_tts_amd import modeling
+
+    for name in ("ParlerTTSForConditionalGeneration", "ParlerTTSForCausalLM", "DACModel"):
+        assert hasattr(modeling, name)
+    import inspect
+
+    sig = inspect.signature(modeling.ParlerTTSForConditionalGeneration.generate)
+    assert list(sig.parameters)[:8] == ["self", "inputs", "generation_config", "logits_processor", "stopping_criteria",
+                                        "synced_gpus", "streamer", "kwargs"]
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from parler_tts_amd import _hip
+
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_hip.HipLibraryMissing):
+        _hip.load_library()
+
+
+def test_config_roundtrip_and_mini_numbers(tmp_path):
+    from parler_tts_amd import ParlerTTSConfig, mini_v01_config
+    from parler_tts_amd.weights import all_keys
+
+    cfg = mini_v01_config()
+    cfg.save_pretrained(str(tmp_path))
+    again = ParlerTTSConfig.from_pretrained(str(tmp_path))
+    assert again == cfg and again.sampling_rate == 44100
+    d = cfg.decoder
+    assert (d.vocab_size, d.hidden_size, d.num_hidden_layers, d.num_attention_heads, d.ffn_dim, d.num_codebooks) == \
+        (1088, 1024, 24, 16, 4096, 9)
+    n_dec = sum(int(__import__("numpy").prod(s)) for k, s in all_keys(cfg).items() if k.startswith("decoder."))
+    assert abs(n_dec / 1e6 - 427.1) < 0.2      # SURVEY.md Appendix A parameter budget
+    with pytest.raises(ValueError):
+        ParlerTTSConfig(vocab_size=3)
+
+
+def test_weight_norm_folding():
+    import torch
+
+    from parler_tts_amd.weights import fold_weight_norm
+
+    v = torch.randn(6, 4, 3)
+    g = torch.rand(6, 1, 1) + 0.5
+    ref = torch._weight_norm(v, g, 0)
+    out = fold_weight_norm({"a.weight_g": g, "a.weight_v": v, "a.bias": torch.zeros(6),
+                            "b.parametrizations.weight.original0": g, "b.parametrizations.weight.original1": v})
+    assert torch.allclose(out["a.weight"], ref, atol=1e-6) and torch.allclose(out["b.weight"], ref, atol=1e-6)
+    assert "a.bias" in out and "a.weight_g" not in out
