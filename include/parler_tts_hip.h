@@ -139,6 +139,12 @@ int ptts_pool_info(ptts_engine* e, int32_t* n_pages, int32_t* max_blocks, int64_
  * steps are launched eagerly. */
 int ptts_set_forced_tokens(ptts_engine* e, const int64_t* tokens_host, int32_t rows);
 
+/* Debug hooks for kernel-level parity tests: stop issuing kernels after n launches of each following
+ * prefill / decode call (-1 = off; while on, steps run eagerly), and expose engine-owned buffers
+ * ("x", "q", "attn_frag", "mlp_frag", "enc_h", "self_pool", "cross_pool", "self_bias", "cross_bias", "tok_in"). */
+int ptts_debug_stop_after(ptts_engine* e, int32_t n_kernels);
+int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* bytes);
+
 /* HIP-event profile of the dominant kernel (self-attention decode): sums over the sampled launches. */
 typedef struct ptts_profile {
     int64_t launches;        /* sampled self-attention launches */

@@ -19,6 +19,7 @@ EXPORTS = [
     "ptts_last_error", "ptts_abi_version", "ptts_create", "ptts_destroy", "ptts_load_tensor", "ptts_weights_ready",
     "ptts_t5_encode", "ptts_prefill", "ptts_decode_steps", "ptts_get_state", "ptts_last_logits",
     "ptts_set_block_table", "ptts_pool_info", "ptts_set_forced_tokens", "ptts_profile_read", "ptts_test_gemm",
+    "ptts_debug_stop_after", "ptts_debug_buffer",
 ]
 
 
@@ -85,6 +86,8 @@ def load_library() -> C.CDLL:
     lib.ptts_pool_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.ptts_set_forced_tokens.argtypes = [vp, i64p, i32]
     lib.ptts_profile_read.argtypes = [vp, C.POINTER(PttsProfile), i32]
+    lib.ptts_debug_stop_after.argtypes = [vp, i32]
+    lib.ptts_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.ptts_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, i32, vp, vp, C.c_float, i32, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ptts_last_error",):

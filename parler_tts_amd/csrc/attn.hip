@@ -29,18 +29,20 @@ template <> struct KVLoad<PBF16> {
     static __device__ inline void unpack(const raw_t& r, float* f) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f[2 * i] = __builtin_bit_cast(float, r[i] << 16);
-            f[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+            const uint32_t w = r[i];
+            f[2 * i] = __builtin_bit_cast(float, w << 16);
+            f[2 * i + 1] = __builtin_bit_cast(float, w & 0xffff0000u);
         }
     }
 };
 template <> struct KVLoad<PF32> {
     static constexpr int LPT = 16;
     static constexpr int EPL = 4;
-    typedef u32x4 raw_t;
+    typedef f32x4 raw_t;
     static __device__ inline void unpack(const raw_t& r, float* f) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, r[i]);
+        // (a bit_cast of an ext-vector ELEMENT lvalue reads element 0 for every index under hipcc 7.2:
+        //  keep this a plain element copy)
+        f[0] = r[0]; f[1] = r[1]; f[2] = r[2]; f[3] = r[3];
     }
 };
 

@@ -108,10 +108,15 @@ struct ptts_engine {
     long long* raw_ids = nullptr;
     const long long* prompt_ids = nullptr;
     int host_pos = 0, host_cur = 0;
+    // work stream used when the caller hands us the (uncapturable) legacy NULL stream
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     // graphs
     hipGraphExec_t step_graph = nullptr;
     ptts_sampling graph_sp = {};
     bool no_graph = false;
+    // debug: stop issuing kernels after dbg_stop launches of the current API call (-1 = off)
+    int dbg_stop = -1, dbg_count = 0;
     // profile
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
@@ -119,6 +124,23 @@ struct ptts_engine {
 };
 
 namespace {
+
+// The legacy NULL stream cannot be captured into a hipGraph.  When the caller passes it, the work runs
+// on the engine's own stream, fenced with events on both sides so the caller-visible ordering is the
+// same as if it had run on the NULL stream.
+int enter_stream(ptts_engine* e, void* user, hipStream_t* s) {
+    if (user) { *s = (hipStream_t)user; return PTTS_OK; }
+    HIP_TRY(hipEventRecord(e->ev_in, nullptr));
+    HIP_TRY(hipStreamWaitEvent(e->own_stream, e->ev_in, 0));
+    *s = e->own_stream;
+    return PTTS_OK;
+}
+int leave_stream(ptts_engine* e, void* user, hipStream_t s) {
+    if (user) return PTTS_OK;
+    HIP_TRY(hipEventRecord(e->ev_out, s));
+    HIP_TRY(hipStreamWaitEvent(nullptr, e->ev_out, 0));
+    return PTTS_OK;
+}
 
 int dev_alloc(ptts_engine* e, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -154,11 +176,12 @@ bool parse_idx(const std::string& name, const std::string& prefix, int* idx, std
     return true;
 }
 
-int ensure_packed(ptts_engine* e, Packed* w, int N, int K) {
+int ensure_packed(ptts_engine* e, Packed* w, int N, int K, hipStream_t s) {
     if (w->ptr) return PTTS_OK;
     int Np = (N + 15) / 16 * 16;
     PTTS_TRY(dev_alloc(e, &w->ptr, (size_t)Np * K * e->esz));
-    HIP_TRY(hipMemset(w->ptr, 0, (size_t)Np * K * e->esz));
+    // same stream as the pack kernels: the engine stream does not synchronise with the NULL stream
+    HIP_TRY(hipMemsetAsync(w->ptr, 0, (size_t)Np * K * e->esz, s));
     w->N = Np;
     w->K = K;
     return PTTS_OK;
@@ -168,7 +191,7 @@ int load_packed(ptts_engine* e, Packed* w, int Ntot, int K, int n_off, int n_str
                 int ndim, int Nsrc, hipStream_t s) {
     if (ndim != 2 || shape[0] != Nsrc || shape[1] != K)
         return fail(PTTS_E_INVALID, "weight shape mismatch: expected [%d,%d]", Nsrc, K);
-    PTTS_TRY(ensure_packed(e, w, Ntot, K));
+    PTTS_TRY(ensure_packed(e, w, Ntot, K, s));
     HIP_TRY(pack_weight_launch(data, w->ptr, Nsrc, K, n_off, n_stride, e->dt, s));
     return PTTS_OK;
 }
@@ -188,6 +211,8 @@ int load_table(ptts_engine* e, void** dst, size_t total, size_t off, size_t n, c
     return PTTS_OK;
 }
 
+#define DBG_GATE(e) do { if ((e)->dbg_stop >= 0 && (e)->dbg_count++ >= (e)->dbg_stop) return PTTS_OK; } while (0)
+
 // ---- one decoder layer stack over B_eff rows at the current position (decode token or prompt token) ----
 int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
     const ptts_config& c = e->cfg;
@@ -202,6 +227,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.eps = 1e-5f;
         g.epi = EPI_QKV_SELF; g.out = e->q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
         g.state = e->state; g.D = D;
+        DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         // self attention over pos+1 cached tokens
         AttnArgs a;
@@ -215,38 +241,45 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
             ep->bytes = 2.0 * M * (double)(e->host_pos + 1) * D * (double)e->esz;
             HIP_TRY(hipEventRecord(ep->a, s));
         }
+        DBG_GATE(e);
         HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
         if (ep) HIP_TRY(hipEventRecord(ep->b, s));
         // out_proj + residual (M:380, M:460)
         g = GemmArgs();
         g.W = w.o.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
         g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         // LN2 + cross-attention query (M:467-471)
         g = GemmArgs();
         g.W = w.cq.ptr; g.N = D; g.K = D; g.M = M;
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.eps = 1e-5f;
         g.epi = EPI_Q_SCALE; g.out = e->q; g.ldo = D; g.scale = scale;
+        DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294)
         a = AttnArgs();
         a.q = e->q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
         a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS;
         a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = e->attn_frag; a.D = D;
+        DBG_GATE(e);
         HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
         g = GemmArgs();
         g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
         g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         // LN3 + fc1 + GELU(erf) -> fragments ; fc2 + residual (M:486-492)
         g = GemmArgs();
         g.W = w.fc1.ptr; g.N = F; g.K = D; g.M = M;
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.eps = 1e-5f;
         g.epi = EPI_ACT_FRAG; g.act = ACT_GELU; g.ofrag = e->mlp_frag; g.ldo = F;
+        DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         g = GemmArgs();
         g.W = w.fc2.ptr; g.N = D; g.K = F; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->mlp_frag;
         g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
     }
     return PTTS_OK;
@@ -268,8 +301,10 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
         step_ev->kind = 1; step_ev->bytes = 0;
         HIP_TRY(hipEventRecord(step_ev->a, s));
     }
+    DBG_GATE(e);
     HIP_TRY(embed_codebooks_launch(embed_args(e), e->B_eff, e->dt, s));
     PTTS_TRY(run_layers(e, s, profile));
+    DBG_GATE(e);
     // final LayerNorm (M:959) + the K LM heads (M:1143) -> logits [B_eff][K][Vp]
     GemmArgs g;
     g.W = e->heads.ptr; g.N = c.codebooks * e->Vp; g.K = c.hidden; g.M = e->B_eff;
@@ -353,6 +388,12 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->layers.resize(cfg->layers);
     e->t5.resize(cfg->t5_layers > 0 ? cfg->t5_layers : 0);
     e->no_graph = getenv("PTTS_NO_GRAPH") != nullptr;
+    if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming) != hipSuccess) {
+        delete e;
+        return fail(PTTS_E_HIP, "could not create the engine stream/events");
+    }
     const int Bm = cfg->max_batch, D = cfg->hidden, F = cfg->ffn, K = cfg->codebooks;
     e->mtiles = (Bm + 31) / 32;
     const int rows = e->mtiles * 32;
@@ -412,6 +453,9 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
 int ptts_destroy(ptts_engine* e) {
     if (!e) return PTTS_OK;
     drop_graph(e);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
@@ -420,7 +464,8 @@ int ptts_destroy(ptts_engine* e) {
 
 int ptts_load_tensor(ptts_engine* e, const char* cname, const float* data, const int64_t* shape, int32_t ndim, void* stream) {
     if (!e || !cname || !data || !shape) return fail(PTTS_E_INVALID, "null argument");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
     const ptts_config& c = e->cfg;
     const int D = c.hidden, F = c.ffn, V = c.vocab, K = c.codebooks;
     std::string name(cname), rest;
@@ -491,6 +536,7 @@ int ptts_load_tensor(ptts_engine* e, const char* cname, const float* data, const
     } else known = false;
     if (!known) return fail(PTTS_E_INVALID, "unknown tensor name '%s'", cname);
     if (rc == PTTS_OK) e->loaded.insert(name);
+    if (rc == PTTS_OK) rc = leave_stream(e, stream, s);
     return rc;
 }
 
@@ -545,7 +591,8 @@ int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_id
     const ptts_config& c = e->cfg;
     if (c.t5_layers <= 0 || !e->t5_shared) return fail(PTTS_E_STATE, "engine was created without a text encoder");
     if (B <= 0 || B > c.max_batch || T <= 0 || T > c.max_desc_len) return fail(PTTS_E_INVALID, "B=%d T=%d outside the engine limits", B, T);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
     const int d = c.enc_hidden, inner = c.t5_heads * c.t5_dkv, ff = c.t5_dff, M = B * T;
     HIP_TRY(t5_embed_launch((const long long*)input_ids, e->t5_shared, e->t5_x, M, d, e->dt, s));
     for (int l = 0; l < c.t5_layers; ++l) {
@@ -574,7 +621,7 @@ int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_id
         PTTS_TRY(launch_gemm(e, g, s));
     }
     HIP_TRY(rmsnorm_rows_launch(e->t5_x, e->t5_final_ln, out, M, d, c.t5_eps, s));
-    return PTTS_OK;
+    return leave_stream(e, stream, s);
 }
 
 int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P, int32_t L, const float* enc_states,
@@ -588,7 +635,9 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
         return fail(PTTS_E_INVALID, "T=%d P=%d L=%d outside the engine limits (%d, %d, %d)", T, P, L, c.max_desc_len, c.max_prompt_len, c.max_length);
     if (P > 0 && !prompt_ids) return fail(PTTS_E_INVALID, "prompt_ids missing");
     if (start_len < 1 || start_len >= L) return fail(PTTS_E_INVALID, "start_len=%d must be in [1, L)", start_len);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
+    e->dbg_count = 0;
     drop_graph(e);
     e->B = B; e->B_eff = B_eff; e->T = T; e->P = P; e->L = L;
     e->pattern = (const long long*)pattern; e->raw_ids = (long long*)raw_ids; e->prompt_ids = (const long long*)prompt_ids;
@@ -626,9 +675,12 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     HIP_TRY(hipStreamSynchronize(s));
     // the P prompt positions, one cached position at a time (causal attention == incremental decode)
     for (int p = 0; p < P; ++p) {
+        if (e->dbg_stop >= 0 && e->dbg_count >= e->dbg_stop) break;
+        e->dbg_count++;
         HIP_TRY(embed_prompt_launch(embed_args(e), B_eff, e->dt, s));
         e->host_pos = p;
         PTTS_TRY(run_layers(e, s, false));
+        if (e->dbg_stop >= 0 && e->dbg_count >= e->dbg_stop) break;
         HIP_TRY(advance_prompt_launch(e->state, s));
     }
     e->host_pos = P;
@@ -636,7 +688,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     HIP_TRY(init_tokens_launch(e->raw_ids, e->pattern, e->tok_in, B * c.codebooks, B_eff * c.codebooks, L, start_len - 1, s));
     e->use_force = false;
     e->prefilled = true;
-    return PTTS_OK;
+    return leave_stream(e, stream, s);
 }
 
 int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, int32_t profile_every, void* stream) {
@@ -644,9 +696,11 @@ int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, 
     if (!e->prefilled) return fail(PTTS_E_STATE, "ptts_prefill has not run");
     if (sp->do_sample && !(sp->temperature > 0.f)) return fail(PTTS_E_INVALID, "temperature must be > 0");
     if (sp->guidance_scale > 1.0f && e->B_eff != 2 * e->B) return fail(PTTS_E_INVALID, "guidance needs B_eff = 2B");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
     int remaining = e->L - e->host_cur;
     if (n_steps > remaining) n_steps = remaining;
+    e->dbg_count = 0;
     const bool forced = e->use_force;
     for (int i = 0; i < n_steps; ++i) {
         const bool prof = profile_every > 0 && ((e->host_cur - 1) % profile_every == 0);
@@ -661,7 +715,7 @@ int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, 
                 }
             }
         }
-        if (prof || e->no_graph || forced) {
+        if (prof || e->no_graph || forced || e->dbg_stop >= 0) {
             PTTS_TRY(run_decode_step(e, *sp, s, prof));
         } else {
             if (!e->step_graph || !same_sampling(e->graph_sp, *sp)) PTTS_TRY(capture_step_graph(e, *sp, s));
@@ -670,14 +724,16 @@ int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, 
         e->host_pos += 1;
         e->host_cur += 1;
     }
-    return PTTS_OK;
+    return leave_stream(e, stream, s);
 }
 
 int ptts_get_state(ptts_engine* e, ptts_state* out, void* stream) {
     if (!e || !out) return fail(PTTS_E_INVALID, "null argument");
     StepState st;
-    HIP_TRY(hipMemcpyAsync(&st, e->state, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
+    HIP_TRY(hipMemcpyAsync(&st, e->state, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     out->pos = st.pos; out->cur_len = st.cur_len; out->prompt_len = st.prompt_len;
     out->n_unfinished = st.n_unfinished; out->done_len = st.done_len; out->step_count = st.step_count;
     return PTTS_OK;
@@ -721,6 +777,31 @@ int ptts_set_forced_tokens(ptts_engine* e, const int64_t* tokens_host, int32_t r
     if (rows != e->B * e->cfg.codebooks) return fail(PTTS_E_INVALID, "rows must be B*K");
     HIP_TRY(hipMemcpy(e->force, tokens_host, sizeof(long long) * rows, hipMemcpyHostToDevice));
     e->use_force = true;
+    return PTTS_OK;
+}
+
+int ptts_debug_stop_after(ptts_engine* e, int32_t n_kernels) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    e->dbg_stop = n_kernels;
+    return PTTS_OK;
+}
+
+int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* bytes) {
+    if (!e || !name || !ptr || !bytes) return fail(PTTS_E_INVALID, "null argument");
+    const ptts_config& c = e->cfg;
+    const size_t rows = (size_t)e->mtiles * 32;
+    std::string n(name);
+    if (n == "x") { *ptr = e->x; *bytes = rows * c.hidden * 4; }
+    else if (n == "q") { *ptr = e->q; *bytes = rows * c.hidden * 4; }
+    else if (n == "attn_frag") { *ptr = e->attn_frag; *bytes = rows * c.hidden * e->esz; }
+    else if (n == "mlp_frag") { *ptr = e->mlp_frag; *bytes = rows * c.ffn * e->esz; }
+    else if (n == "enc_h") { *ptr = e->enc_h; *bytes = ((size_t)c.max_batch * c.max_desc_len + 32) * c.hidden * 4; }
+    else if (n == "self_pool") { *ptr = e->self_pool; *bytes = (int64_t)e->self_pages * c.layers * 2 * c.heads * 4096 * e->esz; }
+    else if (n == "cross_pool") { *ptr = e->cross_pool; *bytes = (int64_t)c.max_batch * e->cross_blocks * c.layers * 2 * c.heads * 4096 * e->esz; }
+    else if (n == "cross_bias") { *ptr = e->cross_bias; *bytes = (int64_t)c.max_batch * e->cross_blocks * 64 * 4; }
+    else if (n == "self_bias") { *ptr = e->self_bias; *bytes = (int64_t)c.max_batch * e->s_cap * 4; }
+    else if (n == "tok_in") { *ptr = e->tok_in; *bytes = rows * c.codebooks * 4; }
+    else return fail(PTTS_E_INVALID, "unknown buffer '%s'", name);
     return PTTS_OK;
 }
 

@@ -151,9 +151,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     const int ld = kc + PAD;
     elem_t* xs = reinterpret_cast<elem_t*>(smem);
     size_t off = STAGE ? (((size_t)32 * ld * sizeof(elem_t) + 15) & ~(size_t)15) : 0;
-    float* stats = reinterpret_cast<float*>(smem + off);   // mean[32], rstd[32]
-    off += 64 * sizeof(float);
-    float* red = reinterpret_cast<float*>(smem + off);      // [NW][NB][2][64] float4
+    // K-split partial sums [NW][NB][2][64] float4: reuse the stage image once every wave is done with it
+    float* red = reinterpret_cast<float*>(smem);
+    (void)off;
 
     f32x4 acc[NB][2];
 #pragma unroll
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 
     // ---- K-split reduction in fixed wave order, then the fused epilogue ----
     f32x4* redv = reinterpret_cast<f32x4*>(red);
+    if (STAGE) __syncthreads();   // all B-fragment reads of the stage image have retired
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         redv[((w * NB + i) * 2 + 0) * 64 + lane] = acc[i][0];
@@ -301,7 +302,8 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int PAD = 16 / (int)sizeof(typename P::elem_t);
     int kc = STAGE ? (a.K < KC ? a.K : KC) : 0;
     size_t lds = STAGE ? ((((size_t)32 * (kc + PAD) * sizeof(typename P::elem_t)) + 15) & ~(size_t)15) : 0;
-    lds += 64 * sizeof(float) + (size_t)NW * NB * 2 * 64 * 16;
+    const size_t red_bytes = (size_t)NW * NB * 2 * 64 * 16;
+    if (lds < red_bytes) lds = red_bytes;
     dim3 grid((a.N + 16 * NB - 1) / (16 * NB), (a.M + 31) / 32);
     auto kern = gemm_kernel<P, NW, NB, STAGE>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);

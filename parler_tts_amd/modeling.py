@@ -97,6 +97,7 @@ class HipEngine:
 
     def _upload(self, sd: Dict[str, torch.Tensor], with_t5: bool) -> None:
         n = 0
+        staged = []   # the fp32 staging copies must outlive the asynchronous pack kernels that read them
         for name, t in sd.items():
             if name.startswith("audio_encoder."):
                 continue
@@ -105,11 +106,14 @@ class HipEngine:
             g = t.to(device=self.device, dtype=torch.float32).contiguous()
             shape = (C.c_int64 * g.dim())(*g.shape)
             _hip.check(self.lib.ptts_load_tensor(self.handle, name.encode(), _ptr(g), shape, g.dim(), _stream()))
+            staged.append(g)
             n += g.numel()
             if n > 200_000_000:  # bound the transient fp32 staging copies
                 torch.cuda.synchronize(self.device)
+                staged.clear()
                 n = 0
         torch.cuda.synchronize(self.device)
+        staged.clear()
         _hip.check(self.lib.ptts_weights_ready(self.handle))
 
     def close(self):

@@ -262,7 +262,9 @@ def test_sampling_probabilities_and_determinism(hip):
     p = run(7, 8)
     ref = torch.softmax(cpu_ref.warp_logits(torch.from_numpy(f["step_logits"][:8]), 0.7, 50), dim=-1)
     assert (p - ref).abs().max() < 1e-5
-    assert ((p > 0).sum(-1) == 50).all()            # exactly top-k survivors (no ties in the fixture)
+    # same survivors as the reference's top-k rule: ties at the k-th value are all kept (the zeroed
+    # LM-head rows of the synthetic model tie at logit 0, so more than k entries can survive)
+    assert torch.equal(p > 0, ref > 0) and ((p > 0).sum(-1) >= 50).all()
     assert torch.equal(p, run(7, 8))
 
     # free-running draws: same seed -> same ids, different seed -> different ids

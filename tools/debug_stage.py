@@ -1,0 +1,120 @@
+"""GPU-box debugging aid: run the prefill kernel by kernel (ptts_debug_stop_after) and diff the engine's
+internal buffers against oracle intermediates for prompt position 0.  Not part of the product."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn.functional as F
+from oracle import cpu_ref
+from parler_tts_amd import _hip
+from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+from parler_tts_amd.delay_pattern import build_delay_pattern_mask
+from tests.helpers import load_case, state_dict_for, case_inputs
+
+dtype = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+name = "tiny_greedy"
+f, meta = load_case(name)
+cfg, sd = state_dict_for(name, meta)
+model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=dtype)
+desc, amask, prompt, pmask = case_inputs(f)
+B, T = desc.shape; P = prompt.shape[1]; L = int(f["max_length"]); K = cfg.decoder.num_codebooks
+D = cfg.decoder.hidden_size; H = cfg.decoder.num_attention_heads; Fd = cfg.decoder.ffn_dim
+eng = model.engine(B, T, P, L)
+lib = eng.lib
+
+def buf(nm, shape, dt=torch.float32):
+    p, n = C.c_void_p(), C.c_int64()
+    _hip.check(lib.ptts_debug_buffer(eng.handle, nm.encode(), C.byref(p), C.byref(n)))
+    numel = int(np.prod(shape))
+    out = torch.empty(numel, dtype=dt, device="cuda")
+    torch.cuda.synchronize()
+    from parler_tts_amd.modeling import _hipMemcpyDtoD
+    assert _hipMemcpyDtoD(out.data_ptr(), p.value, numel * out.element_size()) == 0
+    return out.cpu().reshape(shape)
+
+def defrag(flat, rows, Kf):
+    # fp32 frag layout -> [rows][Kf]
+    r = torch.arange(rows)[:, None]; k = torch.arange(Kf)[None, :]
+    if dtype == "fp32":
+        off = (((k >> 4) * 2 + (r >> 4)) << 8) + ((((r & 15) + 16 * (k & 3)) << 2) + ((k & 15) >> 2))
+    else:
+        off = (((k >> 5) * 2 + (r >> 4)) << 9) + ((((r & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7))
+    return flat[off]
+
+def run(stop):
+    dev = "cuda:0"
+    ids = torch.full((B * K, 1), cfg.decoder.bos_token_id, dtype=torch.long)
+    ids, pattern = build_delay_pattern_mask(ids, cfg.decoder.bos_token_id, cfg.decoder.pad_token_id, L, K)
+    pattern = pattern.to(dev).contiguous()
+    raw = torch.full((B * K, L), cfg.decoder.pad_token_id, dtype=torch.long, device=dev); raw[:, :1] = ids.to(dev)
+    _hip.check(lib.ptts_debug_stop_after(eng.handle, stop))
+    eng.prefill(B, B, torch.from_numpy(f["enc_t5"]).to(dev).contiguous(), amask.to(dev, torch.int32).contiguous(),
+                prompt.to(dev).contiguous(), None, pattern, raw, 1)
+    torch.cuda.synchronize()
+
+def rd(nm, x):
+    return x.float() if dtype == "bf16" else x
+
+fdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+# oracle intermediates, position 0
+pre = "decoder.model.decoder."
+enc_h = cpu_ref.encoder_glue(cfg, sd, torch.from_numpy(f["enc_t5"]), amask)
+x0 = F.embedding(prompt[:, 0], sd["embed_prompts.weight"]) + sd[pre + "embed_positions.weights"][0]
+def cmp(tag, got, want):
+    print(f"{tag:28s} maxdiff {float((got - want).abs().max()):.3e}   ref absmax {float(want.abs().max()):.3e}")
+
+run(0); cmp("enc_h", buf("enc_h", (B * T, D)), enc_h.reshape(B * T, D))
+run(1); cmp("x after embed", buf("x", (32, D))[:B], x0)
+x = x0; scale = 64 ** -0.5
+for l in range(cfg.decoder.num_hidden_layers):
+    p = f"{pre}layers.{l}."
+    base = 1 + 8 * l
+    h = F.layer_norm(x, (D,), sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
+    q = F.linear(h, sd[p + "self_attn.q_proj.weight"]) * scale
+    k = F.linear(h, sd[p + "self_attn.k_proj.weight"]); v = F.linear(h, sd[p + "self_attn.v_proj.weight"])
+    run(base + 1); cmp(f"L{l} q", buf("q", (32, D))[:B], q)
+    # self pool: page = [L][2][H][64][64]; utterance b page b*max_blocks
+    n_pages, max_blocks, page_bytes = eng.pool_info()
+    pe = page_bytes // (4 if dtype == "fp32" else 2)
+    pool = buf("self_pool", (n_pages, cfg.decoder.num_hidden_layers, 2, H, 64, 64), fdt).float()
+    kk = pool[torch.arange(B) * max_blocks, l, 0, :, 0, :].reshape(B, D); vv = pool[torch.arange(B) * max_blocks, l, 1, :, 0, :].reshape(B, D)
+    cmp(f"L{l} k cache", kk, k); cmp(f"L{l} v cache", vv, v)
+    o = v  # one key
+    run(base + 2); cmp(f"L{l} self-attn o", defrag(buf("attn_frag", (32 * D,), fdt).float(), 32, D)[:B], o)
+    x = x + F.linear(o, sd[p + "self_attn.out_proj.weight"])
+    run(base + 3); cmp(f"L{l} x after o-proj", buf("x", (32, D))[:B], x)
+    h = F.layer_norm(x, (D,), sd[p + "encoder_attn_layer_norm.weight"], sd[p + "encoder_attn_layer_norm.bias"])
+    q = F.linear(h, sd[p + "encoder_attn.q_proj.weight"]) * scale
+    run(base + 4); cmp(f"L{l} cross q", buf("q", (32, D))[:B], q)
+    ck = F.linear(enc_h, sd[p + "encoder_attn.k_proj.weight"]).view(B, T, H, 64).transpose(1, 2)
+    cv = F.linear(enc_h, sd[p + "encoder_attn.v_proj.weight"]).view(B, T, H, 64).transpose(1, 2)
+    cpool = buf("cross_pool", (B, cfg.decoder.num_hidden_layers, 2, H, 64, 64), fdt).float()
+    cmp(f"L{l} cross K cache", cpool[:, l, 0, :, :T, :], ck); cmp(f"L{l} cross V cache", cpool[:, l, 1, :, :T, :], cv)
+    qh = q.view(B, 1, H, 64).transpose(1, 2)
+    w = torch.softmax(qh @ ck.transpose(2, 3), dim=-1)
+    o = (w @ cv).transpose(1, 2).reshape(B, D)
+    run(base + 5); cmp(f"L{l} cross-attn o", defrag(buf("attn_frag", (32 * D,), fdt).float(), 32, D)[:B], o)
+    x = x + F.linear(o, sd[p + "encoder_attn.out_proj.weight"])
+    run(base + 6); cmp(f"L{l} x after co-proj", buf("x", (32, D))[:B], x)
+    h = F.layer_norm(x, (D,), sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
+    a = F.gelu(F.linear(h, sd[p + "fc1.weight"]))
+    run(base + 7); cmp(f"L{l} gelu(fc1)", defrag(buf("mlp_frag", (32 * Fd,), fdt).float(), 32, Fd)[:B], a)
+    x = x + F.linear(a, sd[p + "fc2.weight"])
+    run(base + 8); cmp(f"L{l} x after fc2", buf("x", (32, D))[:B], x)
+_hip.check(lib.ptts_debug_stop_after(eng.handle, -1))
+# ---- detail: self-attention output of layer 0 at position 0 (one key: o must equal v)
+run(3)
+p = f"{pre}layers.0."
+h = F.layer_norm(x0, (D,), sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
+v = F.linear(h, sd[p + "self_attn.v_proj.weight"])
+flat = buf("attn_frag", (32 * D,), fdt).float()
+got = defrag(flat, 32, D)[:B]
+torch.set_printoptions(precision=4, linewidth=200)
+print("want b0:", v[0, :16]); print("got  b0:", got[0, :16])
+print("want b0 h1:", v[0, 64:80]); print("got  b0 h1:", got[0, 64:80])
+# where do the wanted values live in the flat buffer?
+for d in (0, 1, 5, 64):
+    idx = (flat - v[0, d]).abs().argmin().item()
+    print("v[0,%d]=%.5f found at flat index %d (val %.5f); expected index %d" % (d, v[0, d], idx, flat[idx], 0))
+_hip.check(lib.ptts_debug_stop_after(eng.handle, -1))
