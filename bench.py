@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the generate() hot path: codec tokens/s + real-time factor, parler_tts_mini_v0.1, greedy, batch 32.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one full ``ParlerTTSForConditionalGeneration.generate()`` pass over one batch of synthetic
+(description, prompt) pairs per GPU: T5 encoder -> prefill -> (max_length-1) decode steps -> un-delay ->
+DAC decode to waveforms.  Inputs are resident in HBM before the timed region.  Weights are random-init
+at the named architecture (no checkpoints offline): ``data = "synthetic"``.
+
+Extra objects on the JSON line (see DESIGN.md "Measurement"):
+  roofline     - the dominant kernel (self-attention decode over the paged KV cache): algorithmic bytes
+                 per launch / average launch duration, measured with HIP events recorded on the engine's
+                 stream around every launch of the kernel in every ``--profile-every``-th decode step of
+                 the timed region
+  cpu_baseline - the oracle (CPU port of the reference's decode loop, oracle/cpu_ref.py, token-identical
+                 to the reference on the golden fixtures) timed on this box's host cores on a bounded
+                 sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def synth_inputs(cfg, B, T, P, seed):
+    g = torch.Generator().manual_seed(seed)
+    desc = torch.randint(2, min(32100, cfg.text_encoder.vocab_size), (B, T), generator=g)
+    prompt = torch.randint(2, min(32100, cfg.vocab_size), (B, P), generator=g)
+    return desc, prompt
+
+
+def cpu_baseline(cfg, sd, B, T, P, L, budget_s=25.0):
+    """Bounded sample of the CPU port on the same workload: decode steps at the start of the run
+    (S ~ P) and in the middle (S ~ L/2) with the reference's cat-grown KV cache, integrated over the
+    whole run with the linear-in-S cost model of BASELINE.md section 4."""
+    from oracle import cpu_ref
+
+    torch.manual_seed(0)
+    dec = cfg.decoder
+    K, D, H = dec.num_codebooks, dec.hidden_size, dec.num_attention_heads
+    enc_h = torch.randn(B, T, D) * 0.1
+    amask = torch.ones(B, T, dtype=torch.long)
+
+    def timed_steps(S0, n):
+        # KV cache of S0 positions filled with noise (values do not change the cost), reference-shaped
+        # cat-grown self K/V (M:303-304) and pre-projected cross K/V (M:287-294)
+        cache = cpu_ref.KVCache("cat")
+        for _ in range(dec.num_hidden_layers):
+            cache.self_k.append(torch.randn(B, H, S0, D // H) * 0.1)
+            cache.self_v.append(torch.randn(B, H, S0, D // H) * 0.1)
+            cache.cross_k.append(torch.randn(B, H, T, D // H) * 0.1)
+            cache.cross_v.append(torch.randn(B, H, T, D // H) * 0.1)
+        cache.length = S0
+        ids = torch.randint(0, 1024, (B * K, 1))
+        cpu_ref.decoder_forward(cfg, sd, ids, enc_h, amask, None, None, cache)   # warm-up
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            cpu_ref.decoder_forward(cfg, sd, ids, enc_h, amask, None, None, cache)
+            ts.append(time.perf_counter() - t0)
+        return sum(ts) / len(ts), cache.length
+
+    # pick the thread count that serves the CPU best on this box (oversubscription hurts small GEMMs)
+    best = None
+    for nt in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        t, _ = timed_steps(P + 1, 2)
+        if best is None or t < best[0]:
+            best = (t, nt)
+    cores = best[1]
+    torch.set_num_threads(cores)
+    t_lo, s_lo = timed_steps(P + 1, 6)
+    s_mid = P + L // 2
+    n_hi = max(2, min(6, int((budget_s - 6 * t_lo) / max(t_lo * 6, 1e-3))))
+    t_hi, s_hi = timed_steps(s_mid, n_hi)
+    slope = (t_hi - t_lo) / max(s_hi - s_lo, 1)
+    steps = L - 1
+    total = sum(t_lo + slope * ((P + 1 + i) - s_lo) for i in range(steps))
+    return {
+        "value": round(B * K * steps / total, 2), "unit": "codec tokens/s", "cores": cores, "kind": "port",
+        "sample": (f"decode loop only (no T5/DAC), B={B}: 6 steps at S={s_lo - 6}..{s_lo} ({t_lo * 1e3:.0f} ms/step) and "
+                   f"{n_hi} steps at S~{s_hi} ({t_hi * 1e3:.0f} ms/step), reference-shaped cat-grown KV, fp32, "
+                   f"{cores} torch threads; integrated over {steps} steps with a linear-in-S model"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--max-length", type=int, default=2580)
+    ap.add_argument("--desc-len", type=int, default=40)
+    ap.add_argument("--prompt-len", type=int, default=16)
+    ap.add_argument("--profile-every", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dac", action="store_true", help="stop at codec ids (diagnostic; not the headline)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    B, T, P, L = args.batch, args.desc_len, args.prompt_len, args.max_length
+    K = cfg.decoder.num_codebooks
+    sd = synthetic_state_dict(cfg, seed=1234, never_eos=True)
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=args.dtype, device=dev)
+    model.profile_every = args.profile_every
+    desc, prompt = synth_inputs(cfg, B, T, P, seed=1234 + rank)   # every rank its own utterances (weak scaling)
+    desc, prompt = desc.to(dev), prompt.to(dev)
+    amask = torch.ones(B, T, dtype=torch.long, device=dev)
+    model.audio_encoder  # build the codec before timing
+    kw = dict(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L)
+    if args.no_dac:
+        kw["return_raw_ids"] = True
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    out = None
+    for _ in range(args.warmup):
+        out = model.generate(**kw)
+    sync_all()
+    model.engine().profile_read(reset=True)
+    phase = {"t5_prefill_ms": 0.0, "decode_ms": 0.0, "post_ms": 0.0}
+    model.phase_times = phase
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.generate(**kw)
+        if dist is not None:   # data-parallel plumbing: gather the codec ids of every rank (RCCL over xGMI)
+            codes = model.last_codes[0].to(torch.int16)
+            gathered = [torch.empty_like(codes) for _ in range(world)]
+            dist.all_gather(gathered, codes)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    n_steps = L - 1
+    tokens = B * K * n_steps * args.steps * world
+    F = L - K
+    audio_s = B * F / cfg.audio_encoder.frame_rate * args.steps * world
+    prof = model.engine().profile_read(reset=True)
+    if rank == 0:
+        achieved = (prof.algo_bytes / 1e9) / (prof.total_ms / 1e3) if prof.total_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_attn_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.dtype)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "codec tokens/sec + real-time-factor, parler_tts_mini_v0.1 greedy @ bs32",
+            "value": round(tokens / dt, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"parler_tts_mini_v0.1 {args.dtype}, batch {B}/GPU greedy, T={T} P={P} max_length={L} "
+                                   f"({n_steps} decode steps), full generate() incl. T5 encoder, prefill and DAC decode"
+                                   + (" [DAC skipped]" if args.no_dac else ""),
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "rtf_audio_s_per_wall_s": round(audio_s / dt, 2),
+            "decode_loop_tokens_per_s": round(tokens / world / max(phase["decode_ms"] / 1e3, 1e-9), 1) if phase["decode_ms"] else None,
+            "phase_ms_per_step_rank0": {k: round(v / args.steps, 2) for k, v in phase.items()},
+            "roofline": {
+                "kernel": "attn_decode_kernel (self-attention over the paged KV cache)",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launches_sampled": int(prof.launches),
+                "avg_launch_us": round(prof.total_ms * 1e3 / max(prof.launches, 1), 2),
+                "avg_algo_bytes_per_launch": round(prof.algo_bytes / max(prof.launches, 1)),
+                "sampled_step_ms_eager": round(prof.step_ms / max(prof.steps, 1), 3),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sd_dec = {k: v for k, v in sd.items() if k.startswith("decoder.")}
+            line["cpu_baseline"] = cpu_baseline(cfg, sd_dec, B, T, P, L)
+            line["speedup_vs_cpu_decode_loop"] = round(line["decode_loop_tokens_per_s"] / line["cpu_baseline"]["value"], 1) \
+                if line["decode_loop_tokens_per_s"] else None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

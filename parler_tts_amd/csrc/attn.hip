@@ -99,8 +99,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
             float d = 0.f;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) d = fmaf(q[j], kf[j], d);
-#pragma unroll
-            for (int o = 1; o < LPT; o <<= 1) d += __shfl_xor(d, o);
+            d = (LPT == 8) ? sum_oct(d) : sum_row16(d);   // lanes of one token row (DPP, no LDS crossbar)
             if (c == 0 && tok < S) sc[tok] = bias ? d + bias[tok] : d;
         }
     }
@@ -152,8 +151,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     // lanes with equal c hold partial sums for the same 16-byte chunk: fold the token-lanes
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
-#pragma unroll
-        for (int o = LPT; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
+        if (LPT == 8) acc[j] += dpp_f<0x128>(acc[j]);   // row_ror:8 pairs lane i with i^8 inside a 16-lane row
+        acc[j] += __shfl_xor(acc[j], 16);
+        acc[j] += __shfl_xor(acc[j], 32);
     }
     if (tt == 0) {
 #pragma unroll

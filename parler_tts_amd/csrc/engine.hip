@@ -317,8 +317,7 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
     sa.tok_in = e->tok_in; sa.force = e->use_force ? e->force : nullptr; sa.probs = e->probs;
     sa.pad = c.pad_token_id; sa.eos = c.eos_token_id; sa.do_sample = sp.do_sample; sa.top_k = sp.top_k;
     sa.temperature = sp.temperature; sa.guidance = sp.guidance_scale; sa.seed = sp.seed;
-    HIP_TRY(select_launch(sa, s));
-    HIP_TRY(advance_launch(e->state, e->unf_count, e->L, s));
+    HIP_TRY(select_launch(sa, s));   // the last row to finish also advances pos / cur_len / step_count
     if (step_ev) HIP_TRY(hipEventRecord(step_ev->b, s));
     return PTTS_OK;
 }
@@ -372,6 +371,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     if (cfg->ffn % 32 != 0 || cfg->enc_hidden % 32 != 0) return fail(PTTS_E_UNSUPPORTED, "ffn / enc_hidden must be multiples of 32");
     if (cfg->hidden > (cfg->dtype == PTTS_DTYPE_BF16 ? 2048 : 1024))
         return fail(PTTS_E_UNSUPPORTED, "hidden=%d exceeds the LDS-resident LayerNorm row (2048 bf16 / 1024 f32)", cfg->hidden);
+    if (cfg->codebooks <= 0 || cfg->codebooks > 32) return fail(PTTS_E_UNSUPPORTED, "codebooks must be in [1, 32]");
     if (cfg->max_batch <= 0 || cfg->max_length <= 1 || cfg->max_desc_len <= 0 || cfg->max_prompt_len < 0)
         return fail(PTTS_E_INVALID, "bad limits");
     if (cfg->max_prompt_len + cfg->max_length > cfg->max_positions)

@@ -129,15 +129,18 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE>
+template <typename P, int NW, int NB, bool STAGE, int KI>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
+    // KI: float4 per lane per activation row held in registers by the staged prologue (K chunk <= 256*KI)
     typedef typename P::elem_t elem_t;
     typedef Tile<P> T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSTEP = P::KSTEP, EPL = P::EPL;
     constexpr int TILE = 64 * EPL;                       // elements per 1 KiB tile
-    constexpr int KC = P::IS_BF16 ? 2048 : 1024;         // K chunk parked in LDS (<= 128 KiB + pad)
+    constexpr int KC = 256 * KI;                         // K chunk parked in LDS
     constexpr int PAD = 16 / (int)sizeof(elem_t);        // 16-byte row pad -> conflict-free b128 reads
+    constexpr int RPW = 32 / NW;                         // activation rows per wave
+    constexpr int RB = RPW < 4 ? RPW : 4;                // rows normalised together (ILP across rows)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb0 = blockIdx.x * NB;
@@ -146,88 +149,117 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     const int ksteps = K / KSTEP;
     const elem_t* Wp = reinterpret_cast<const elem_t*>(a.W);
 
-    // LDS carve: [stage image][stats][reduction]
     const int kc = STAGE ? (K < KC ? K : KC) : 0;
     const int ld = kc + PAD;
     elem_t* xs = reinterpret_cast<elem_t*>(smem);
-    size_t off = STAGE ? (((size_t)32 * ld * sizeof(elem_t) + 15) & ~(size_t)15) : 0;
     // K-split partial sums [NW][NB][2][64] float4: reuse the stage image once every wave is done with it
     float* red = reinterpret_cast<float*>(smem);
-    (void)off;
 
     f32x4 acc[NB][2];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { acc[i][0] = {0, 0, 0, 0}; acc[i][1] = {0, 0, 0, 0}; }
 
     const bool norm = STAGE && (a.pro == PRO_LAYERNORM || a.pro == PRO_RMSNORM);
-
     const int cstep = STAGE ? KC / KSTEP : ksteps;   // only the LDS-staged path needs K chunks
+
+    // first burst of this wave's weight tiles: issued before the prologue so HBM latency hides under it
+    typename T::wfrag wt[U][NB];
+    auto load_burst = [&](int ks0, int cend) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = ks0 + u * NW;
+            if (ks < cend) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    wt[u][i] = T::load_global(Wp + ((size_t)(nb0 + i) * ksteps + ks) * TILE + lane * EPL);
+            }
+        }
+    };
+    {
+        const int cend0 = cstep < ksteps ? cstep : ksteps;
+        load_burst(w, cend0);
+    }
+
     for (int c0 = 0; c0 < ksteps; c0 += cstep) {
         const int cend = (c0 + cstep < ksteps) ? c0 + cstep : ksteps;
         if (STAGE) {
-            // ---- wave per row: load fp32 row chunk to registers, (LN | RMS), convert, park in LDS ----
+            // ---- wave per row, RB rows at a time: fp32 rows -> registers, (LN | RMS), convert, park in LDS ----
             if (c0 > 0) __syncthreads();
             const int kbase = c0 * KSTEP, klen = (cend - c0) * KSTEP;
-            for (int r = w; r < 32; r += NW) {
-                const int row = m0 + r;
-                float4 v[8];
-                const float* xr = a.x + (size_t)(row < a.M ? row : a.M - 1) * a.ldx + kbase;
+            for (int rb = 0; rb < RPW; rb += RB) {
+                float4 v[RB][KI];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int k = 4 * lane + 256 * i;
-                    v[i] = (k < klen) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0, 0, 0, 0);
+                for (int j = 0; j < RB; ++j) {
+                    const int row = m0 + w * RPW + rb + j;
+                    const float* xr = a.x + (size_t)(row < a.M ? row : a.M - 1) * a.ldx + kbase;
+#pragma unroll
+                    for (int i = 0; i < KI; ++i) {
+                        const int k = 4 * lane + 256 * i;
+                        v[j][i] = (k < klen) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0, 0, 0, 0);
+                    }
                 }
-                float mean = 0.f, rstd = 1.f;
-                if (norm) {   // whole row is in this chunk (host guarantees K <= KC for LN/RMS)
-                    if (a.pro == PRO_LAYERNORM) {
-                        float s = 0.f;
+                float mean[RB], rstd[RB];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-                        mean = wave_sum(s) / (float)K;
+                for (int j = 0; j < RB; ++j) { mean[j] = 0.f; rstd[j] = 1.f; }
+                if (norm) {   // whole row is in this chunk (host guarantees K <= KC for LN/RMS)
+                    const float invK = 1.0f / (float)K;
+                    if (a.pro == PRO_LAYERNORM) {
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) {
+                            float sm = 0.f;
+#pragma unroll
+                            for (int i = 0; i < KI; ++i) sm += (v[j][i].x + v[j][i].y) + (v[j][i].z + v[j][i].w);
+                            mean[j] = wave_sum(sm) * invK;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
                         float q = 0.f;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            int k = 4 * lane + 256 * i;
-                            if (k < klen) {
-                                float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                        for (int i = 0; i < KI; ++i) {
+                            if (4 * lane + 256 * i < klen) {
+                                const float d0 = v[j][i].x - mean[j], d1 = v[j][i].y - mean[j];
+                                const float d2 = v[j][i].z - mean[j], d3 = v[j][i].w - mean[j];
                                 q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                             }
                         }
-                        rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + a.eps);
-                    } else {
-                        float q = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-                        rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + a.eps);
+                        rstd[j] = 1.0f / sqrtf(wave_sum(q) * invK + a.eps);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int k = 4 * lane + 256 * i;
+                for (int i = 0; i < KI; ++i) {
+                    const int k = 4 * lane + 256 * i;
                     if (k < klen) {
-                        float y[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                        float gg[4] = {1.f, 1.f, 1.f, 1.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
                         if (norm) {
-                            float4 g = *reinterpret_cast<const float4*>(a.gamma + kbase + k);
-                            float gg[4] = {g.x, g.y, g.z, g.w};
+                            const float4 g = *reinterpret_cast<const float4*>(a.gamma + kbase + k);
+                            gg[0] = g.x; gg[1] = g.y; gg[2] = g.z; gg[3] = g.w;
                             if (a.pro == PRO_LAYERNORM) {
-                                float4 bt = *reinterpret_cast<const float4*>(a.beta + kbase + k);
-                                float bb[4] = {bt.x, bt.y, bt.z, bt.w};
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean) * rstd * gg[e] + bb[e];
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) y[e] = gg[e] * (y[e] * rstd);
+                                const float4 bt = *reinterpret_cast<const float4*>(a.beta + kbase + k);
+                                bb[0] = bt.x; bb[1] = bt.y; bb[2] = bt.z; bb[3] = bt.w;
                             }
                         }
-                        elem_t* dst = xs + (size_t)r * ld + k;
-                        if (P::IS_BF16) {
-                            uint2 pk;
-                            pk.x = (uint32_t)float_to_bf16_bits(y[0]) | ((uint32_t)float_to_bf16_bits(y[1]) << 16);
-                            pk.y = (uint32_t)float_to_bf16_bits(y[2]) | ((uint32_t)float_to_bf16_bits(y[3]) << 16);
-                            *reinterpret_cast<uint2*>(dst) = pk;
-                        } else {
-                            *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) {
+                            float y[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
+                            if (norm) {
+                                if (a.pro == PRO_LAYERNORM) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean[j]) * rstd[j] * gg[e] + bb[e];
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) y[e] = gg[e] * (y[e] * rstd[j]);
+                                }
+                            }
+                            elem_t* dst = xs + (size_t)(w * RPW + rb + j) * ld + k;
+                            if (P::IS_BF16) {
+                                uint2 pk;
+                                pk.x = (uint32_t)float_to_bf16_bits(y[0]) | ((uint32_t)float_to_bf16_bits(y[1]) << 16);
+                                pk.y = (uint32_t)float_to_bf16_bits(y[2]) | ((uint32_t)float_to_bf16_bits(y[3]) << 16);
+                                *reinterpret_cast<uint2*>(dst) = pk;
+                            } else {
+                                *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+                            }
                         }
                     }
                 }
@@ -236,16 +268,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         }
         // ---- stream this wave's weight tiles of the chunk ----
         for (int ks0 = c0 + w; ks0 < cend; ks0 += NW * U) {
-            typename T::wfrag wt[U][NB];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int ks = ks0 + u * NW;
-                if (ks < cend) {
-#pragma unroll
-                    for (int i = 0; i < NB; ++i)
-                        wt[u][i] = T::load_global(Wp + ((size_t)(nb0 + i) * ksteps + ks) * TILE + lane * EPL);
-                }
-            }
+            if (ks0 != w) load_burst(ks0, cend);      // the first burst is already in flight
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ks = ks0 + u * NW;
@@ -296,53 +319,60 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE>
+template <typename P, int NW, int NB, bool STAGE, int KI>
 hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
-    constexpr int KC = P::IS_BF16 ? 2048 : 1024;
+    constexpr int KC = 256 * KI;
     constexpr int PAD = 16 / (int)sizeof(typename P::elem_t);
     int kc = STAGE ? (a.K < KC ? a.K : KC) : 0;
     size_t lds = STAGE ? ((((size_t)32 * (kc + PAD) * sizeof(typename P::elem_t)) + 15) & ~(size_t)15) : 0;
     const size_t red_bytes = (size_t)NW * NB * 2 * 64 * 16;
     if (lds < red_bytes) lds = red_bytes;
     dim3 grid((a.N + 16 * NB - 1) / (16 * NB), (a.M + 31) / 32);
-    auto kern = gemm_kernel<P, NW, NB, STAGE>;
+    auto kern = gemm_kernel<P, NW, NB, STAGE, KI>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
 }
 
+// KI (row floats held per lane / 4): 4 covers K <= 1024 per chunk; f32 rows are chunked at 1024 (LDS),
+// bf16 rows up to 2048 use KI = 8
 template <typename P>
 hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     const bool stage = a.pro != PRO_FRAG;
     const int ksteps = a.K / P::KSTEP;
     const bool gated = a.epi == EPI_GATED_FRAG;
-    // waves per workgroup: enough K-split that a wave streams <= ~8 tiles in one burst
-    int nw = ksteps > 64 ? 16 : (ksteps > 32 ? 8 : 4);
     if (gated) {
-        if (stage) return launch_one<P, 4, 2, true>(a, stream);
-        return launch_one<P, 4, 2, false>(a, stream);
+        if (!stage) return launch_one<P, 4, 2, false, 1>(a, stream);
+        if (P::IS_BF16 && a.K > 1024) return launch_one<P, 4, 2, true, 8>(a, stream);
+        return launch_one<P, 4, 2, true, 4>(a, stream);
     }
     if (stage) {
-        if (nw == 16) return launch_one<P, 16, 1, true>(a, stream);
-        if (nw == 8) return launch_one<P, 8, 1, true>(a, stream);
-        return launch_one<P, 4, 1, true>(a, stream);
+        const bool big = P::IS_BF16 && a.K > 1024 && (a.pro == PRO_LAYERNORM || a.pro == PRO_RMSNORM || a.K <= 2048);
+        if (big) return launch_one<P, 8, 1, true, 8>(a, stream);
+        if (ksteps >= 16) return launch_one<P, 8, 1, true, 4>(a, stream);
+        return launch_one<P, 4, 1, true, 4>(a, stream);
     }
-    if (nw == 16) return launch_one<P, 16, 1, false>(a, stream);
-    if (nw == 8) return launch_one<P, 8, 1, false>(a, stream);
-    return launch_one<P, 4, 1, false>(a, stream);
+    // fragment input: enough K-split that a wave streams <= ~8 tiles in one burst
+    const int nw = ksteps > 64 ? 16 : (ksteps > 32 ? 8 : 4);
+    if (nw == 16) return launch_one<P, 16, 1, false, 1>(a, stream);
+    if (nw == 8) return launch_one<P, 8, 1, false, 1>(a, stream);
+    return launch_one<P, 4, 1, false, 1>(a, stream);
 }
 
-template <typename P, int NW, int NB, bool STAGE>
+template <typename P, int NW, int NB, int KI>
 hipError_t allow_big_lds() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<P, NW, NB, STAGE>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<P, NW, NB, true, KI>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <typename P>
 hipError_t init_typed() {
     hipError_t e;
-    if ((e = allow_big_lds<P, 4, 2, true>()) != hipSuccess) return e;
-    if ((e = allow_big_lds<P, 4, 1, true>()) != hipSuccess) return e;
-    if ((e = allow_big_lds<P, 8, 1, true>()) != hipSuccess) return e;
-    if ((e = allow_big_lds<P, 16, 1, true>()) != hipSuccess) return e;
+    if ((e = allow_big_lds<P, 4, 2, 4>()) != hipSuccess) return e;
+    if ((e = allow_big_lds<P, 4, 1, 4>()) != hipSuccess) return e;
+    if ((e = allow_big_lds<P, 8, 1, 4>()) != hipSuccess) return e;
+    if (P::IS_BF16) {
+        if ((e = allow_big_lds<P, 4, 2, 8>()) != hipSuccess) return e;
+        if ((e = allow_big_lds<P, 8, 1, 8>()) != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 

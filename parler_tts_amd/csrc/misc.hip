@@ -8,19 +8,29 @@ namespace {
 // ---- embedding: x[b] = ((((0 + E0[t0]) + E1[t1]) + ...) + E_{K-1}[t_{K-1}]) + pos_table[pos]
 // strictly left-to-right like Python's sum() at M:836, then the position row (M:884-886).
 template <typename P>
-__global__ void embed_codebooks_kernel(EmbedArgs a) {
+__global__ __launch_bounds__(256) void embed_codebooks_kernel(EmbedArgs a) {
     typedef typename P::elem_t elem_t;
+    __shared__ int toks[32];
     const int b = blockIdx.x;
     const int pos = a.state->pos;
+    if ((int)threadIdx.x < a.K) toks[threadIdx.x] = a.tok_in[b * a.K + threadIdx.x];
+    __syncthreads();
     const elem_t* tab = reinterpret_cast<const elem_t*>(a.tables);
     const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)pos * a.D;
+    // the K row gathers of one output element are independent loads (issued together); the sum order
+    // stays strictly left to right
     for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+        float e[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < a.K) e[k] = from_elem<P>(tab[((size_t)k * a.rows + toks[k]) * a.D + d]);
+        const float pe = from_elem<P>(ptab[d]);
         float s = 0.f;
-        for (int k = 0; k < a.K; ++k) {
-            int tok = a.tok_in[b * a.K + k];
-            s = s + from_elem<P>(tab[((size_t)k * a.rows + tok) * a.D + d]);
-        }
-        a.x[(size_t)b * a.D + d] = s + from_elem<P>(ptab[d]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < a.K) s = s + e[k];
+        for (int k = 16; k < a.K; ++k) s = s + from_elem<P>(tab[((size_t)k * a.rows + toks[k]) * a.D + d]);
+        a.x[(size_t)b * a.D + d] = s + pe;
     }
 }
 
@@ -186,6 +196,21 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         const int feed = (int)(forced == -1 ? nxt : forced);
         a.tok_in[row] = feed;
         if (a.guidance > 1.0f) a.tok_in[row + a.rows] = feed;   // both halves see the same ids (M:2112)
+        // the last row to finish advances the loop state (every row has read cur_len/step_count by then)
+        __threadfence();
+        const int ticket = atomicAdd(a.unf_count + 1, 1);
+        if (ticket == a.rows - 1) {
+            __threadfence();
+            StepState* s = a.state;
+            const int unf_total = atomicAdd(a.unf_count, 0);
+            s->pos += 1;
+            s->cur_len += 1;
+            s->step_count += 1;
+            s->n_unfinished = unf_total;
+            if (unf_total == 0 && s->done_len == 0) s->done_len = s->cur_len;
+            a.unf_count[0] = 0;
+            a.unf_count[1] = 0;
+        }
     }
 }
 

@@ -105,14 +105,24 @@ struct StepState {
     int pad_;
 };
 
-// wave64 all-reduce helpers (LDS crossbar shuffles; wave = 64 lanes on gfx950)
+// ---- wave64 all-reduce helpers on DPP (VALU data-parallel primitives: no LDS crossbar round trips) ----
+// gfx9 DPP controls: quad_perm 0x00-0xFF, row_ror:n 0x120+n, row_mirror 0x140, row_half_mirror 0x141.
+template <int CTRL> __device__ inline float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ inline float lane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// after these every lane of a group holds the group's sum
+__device__ inline float sum_quad(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); return v; }   // 4 lanes
+__device__ inline float sum_oct(float v) { v = sum_quad(v); v += dpp_f<0x141>(v); return v; }        // 8 lanes
+__device__ inline float sum_row16(float v) { v = sum_oct(v); v += dpp_f<0x140>(v); return v; }       // 16 lanes
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = sum_row16(v);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }

@@ -234,6 +234,13 @@ class DACModel:
             raise ValueError(f"Expected one frame, got {len(audio_codes)}")
         codes = audio_codes.squeeze(0).to(self.device)
         w, cfg = self.w, self.config
+        # bound the transient activations (96 ch x 512 samples per frame in the last block): a few
+        # utterances at a time for long clips
+        per_utt = codes.shape[-1] * cfg.hop_length * (cfg.decoder_hidden_size // 2 ** len(cfg.upsampling_ratios)) * 4
+        chunk = max(1, min(codes.shape[0], int(6e9 // max(per_utt * 6, 1))))
+        if chunk < codes.shape[0]:
+            outs = [self.decode(codes[i:i + chunk][None], None).audio_values for i in range(0, codes.shape[0], chunk)]
+            return ModelOutput(audio_values=torch.cat(outs, dim=0))
 
         def snake(x, alpha):
             return x + (alpha + 1e-9).reciprocal() * torch.sin(alpha * x).pow(2)
@@ -286,6 +293,7 @@ class ParlerTTSForConditionalGeneration:
         if self.generation_config.bos_token_id is None:
             self.generation_config.bos_token_id = d.bos_token_id  # M:2532 reads it; the recipe leaves it unset
         self.profile_every = 0
+        self.phase_times = None   # bench.py: {'t5_prefill_ms','decode_ms','post_ms'} accumulated with syncs at the seams
 
     # ---- construction ----
     @classmethod
@@ -409,6 +417,15 @@ class ParlerTTSForConditionalGeneration:
             raise NotImplementedError("top_p warping is not implemented on device (top_k and temperature are)")
 
         eng = self.engine(B_eff, T, P, L)
+        import time as _time
+
+        def _tick():
+            if self.phase_times is None:
+                return 0.0
+            torch.cuda.synchronize(dev)
+            return _time.perf_counter()
+
+        t_start = _tick()
         if enc_out is None:
             enc = eng.t5_encode(input_ids, attention_mask)                                   # M:2467-2474
         # classifier-free guidance: zeroed 'null' half (M:2231-2237), prompts repeated (M:2109-2118)
@@ -440,6 +457,7 @@ class ParlerTTSForConditionalGeneration:
         sp.guidance_scale = float(gen.guidance_scale) if use_cfg else 1.0
         sp.seed = int(gen.seed if gen.seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len)
+        t_dec = _tick()
         # ---- the hot loop: state lives on the device, the host only polls for "all rows finished" ----
         remaining = L - start_len
         chunk = 1 if streamer is not None else 128
@@ -462,6 +480,10 @@ class ParlerTTSForConditionalGeneration:
         if streamer is not None:
             streamer.end()
         torch.cuda.current_stream().synchronize()
+        t_post = _tick()
+        if self.phase_times is not None:
+            self.phase_times["t5_prefill_ms"] += (t_dec - t_start) * 1e3
+            self.phase_times["decode_ms"] += (t_post - t_dec) * 1e3
         self.last_raw_ids = raw_ids[:, :L_out]
         # ---- un-delay (M:2633-2648): integer bookkeeping on the device tensors ----
         out_ids = apply_delay_pattern_mask(raw_ids[:, :L_out], pattern)
@@ -471,6 +493,8 @@ class ParlerTTSForConditionalGeneration:
         output_ids = out_ids[keep].reshape(B, K, -1)[None, ...]
         self.last_codes = output_ids
         if model_kwargs.get("return_raw_ids"):
+            if self.phase_times is not None:
+                self.phase_times["post_ms"] += (_tick() - t_post) * 1e3
             return output_ids
         # ---- DAC decode (M:2650-2680) ----
         special = (gen.bos_token_id, gen.pad_token_id, gen.eos_token_id)
@@ -488,6 +512,8 @@ class ParlerTTSForConditionalGeneration:
                 else:
                     vals.append(torch.zeros(1, 1, 1, device=dev))
             values = torch.nn.utils.rnn.pad_sequence(vals, batch_first=True, padding_value=0).squeeze(-1).squeeze(-1)
+        if self.phase_times is not None:
+            self.phase_times["post_ms"] += (_tick() - t_post) * 1e3
         if gen.return_dict_in_generate:
             return ModelOutput(sequences=values)
         return values
