@@ -18,8 +18,8 @@
 
 namespace {
 
-constexpr int NWAVES = 4;
-constexpr int UNR = 8;
+constexpr int NWAVES = 8;
+constexpr int UNR = 4;
 
 template <typename P> struct KVLoad;
 template <> struct KVLoad<PBF16> {
@@ -50,7 +50,9 @@ template <typename P, typename OP>
 __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     typedef typename P::elem_t elem_t;
     typedef KVLoad<P> L;
+    typedef typename L::raw_t raw_t;
     constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT;
+    constexpr int STRIDE = NWAVES * UNR;                          // tiles between two bursts of one wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem);                   // [S_cap] scores -> probabilities
     float* red = sc + a.s_cap;                                    // [NWAVES][64] partial outputs
@@ -74,35 +76,54 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[b * a.pool.max_blocks + i];
     __syncthreads();
     const size_t page_elems = a.pool.page_elems();
-    auto kv_off = [&](int kv, int tok) -> size_t {
-        return (size_t)pages[tok >> 6] * page_elems +
-               ((size_t)((a.layer * 2 + kv) * a.pool.H + h) * PTTS_PAGE_TOKENS + (tok & 63)) * PTTS_HEAD_DIM;
-    };
-
-    // ---------------- pass 1: scores ----------------
+    const size_t head_off = (size_t)(a.layer * 2 * a.pool.H + h) * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM + c * EPL;
+    const size_t v_off = (size_t)a.pool.H * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM;
     const int ntiles = (S + TPW - 1) / TPW;
-    for (int t0 = w; t0 < ntiles; t0 += NWAVES * UNR) {
-        typename L::raw_t kr[UNR];
+
+    // one burst = UNR tiles of 1 KiB, all issued before the first use (plain loads: hipcc counts them)
+    auto load_burst = [&](raw_t (&buf)[UNR], int t0, size_t kv_add) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            int tile = t0 + u * NWAVES;
-            int tok = tile * TPW + tt;
+            int tok = (t0 + u * NWAVES) * TPW + tt;
             if (tok > S - 1) tok = S - 1;
-            kr[u] = *reinterpret_cast<const typename L::raw_t*>(pool + kv_off(0, tok) + c * EPL);
+            buf[u] = *reinterpret_cast<const raw_t*>(pool + (size_t)pages[tok >> 6] * page_elems + head_off + kv_add +
+                                                     (size_t)(tok & 63) * PTTS_HEAD_DIM);
         }
+    };
+    auto score_burst = [&](const raw_t (&buf)[UNR], int t0) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            int tile = t0 + u * NWAVES;
-            int tok = tile * TPW + tt;
+            const int tok = (t0 + u * NWAVES) * TPW + tt;
             float kf[EPL];
-            L::unpack(kr[u], kf);
+            L::unpack(buf[u], kf);
             float d = 0.f;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) d = fmaf(q[j], kf[j], d);
             d = (LPT == 8) ? sum_oct(d) : sum_row16(d);   // lanes of one token row (DPP, no LDS crossbar)
             if (c == 0 && tok < S) sc[tok] = bias ? d + bias[tok] : d;
         }
+    };
+
+    // ---------------- pass 1: scores, bursts double-buffered in registers ----------------
+    raw_t bufA[UNR], bufB[UNR];
+    {
+        int t0 = w;
+        load_burst(bufA, t0, 0);
+        while (true) {
+            bool more = t0 + STRIDE < ntiles;
+            if (more) load_burst(bufB, t0 + STRIDE, 0);
+            score_burst(bufA, t0);
+            if (!more) break;
+            t0 += STRIDE;
+            more = t0 + STRIDE < ntiles;
+            if (more) load_burst(bufA, t0 + STRIDE, 0);
+            score_burst(bufB, t0);
+            if (!more) break;
+            t0 += STRIDE;
+        }
     }
+    // first V burst goes out now: it does not depend on the probabilities and flies under the softmax
+    load_burst(bufA, w, v_off);
     __syncthreads();
 
     // ---------------- softmax over [0, S) ----------------
@@ -111,7 +132,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     m = wave_max(m);
     if (lane == 0) wred[w] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    m = wred[0];
+#pragma unroll
+    for (int i = 1; i < NWAVES; ++i) m = fmaxf(m, wred[i]);
     __syncthreads();
     float sum = 0.f;
     for (int t = tid; t < S; t += NWAVES * 64) {
@@ -122,7 +145,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     sum = wave_sum(sum);
     if (lane == 0) wred[w] = sum;
     __syncthreads();
-    sum = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+    sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVES; ++i) sum += wred[i];
     for (int t = tid; t < S; t += NWAVES * 64) sc[t] = sc[t] / sum;
     __syncthreads();
 
@@ -130,22 +155,30 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     float acc[EPL];
 #pragma unroll
     for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
-    for (int t0 = w; t0 < ntiles; t0 += NWAVES * UNR) {
-        typename L::raw_t vr[UNR];
+    auto pv_burst = [&](const raw_t (&buf)[UNR], int t0) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            int tok = (t0 + u * NWAVES) * TPW + tt;
-            if (tok > S - 1) tok = S - 1;
-            vr[u] = *reinterpret_cast<const typename L::raw_t*>(pool + kv_off(1, tok) + c * EPL);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            int tok = (t0 + u * NWAVES) * TPW + tt;
-            float p = (tok < S) ? sc[tok] : 0.f;
+            const int tok = (t0 + u * NWAVES) * TPW + tt;
+            const float p = (tok < S) ? sc[tok] : 0.f;
             float vf[EPL];
-            L::unpack(vr[u], vf);
+            L::unpack(buf[u], vf);
 #pragma unroll
             for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+        }
+    };
+    {
+        int t0 = w;
+        while (true) {
+            bool more = t0 + STRIDE < ntiles;
+            if (more) load_burst(bufB, t0 + STRIDE, v_off);
+            pv_burst(bufA, t0);
+            if (!more) break;
+            t0 += STRIDE;
+            more = t0 + STRIDE < ntiles;
+            if (more) load_burst(bufA, t0 + STRIDE, v_off);
+            pv_burst(bufB, t0);
+            if (!more) break;
+            t0 += STRIDE;
         }
     }
     // lanes with equal c hold partial sums for the same 16-byte chunk: fold the token-lanes
@@ -161,7 +194,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     }
     __syncthreads();
     if (tid < PTTS_HEAD_DIM) {
-        float o = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWAVES; ++i) o += red[i * 64 + tid];
         typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(b >> 5) * 32 * a.D;
         of[frag_off<OP>(b & 31, h * PTTS_HEAD_DIM + tid)] = to_elem<OP>(o);
     }
