@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 1
+#define PTTS_ABI_VERSION 2
 
 enum { PTTS_DTYPE_F32 = 0, PTTS_DTYPE_BF16 = 1 };
 
@@ -58,6 +58,9 @@ typedef struct ptts_config {
     int32_t max_desc_len;       /* T */
     int32_t max_prompt_len;     /* P */
     int32_t max_length;         /* generation columns L (<= max_positions - P) */
+    /* codec decoder (DACConfig + the descript package defaults); dac_hidden = 0: engine without the codec */
+    int32_t dac_codebook_size, dac_codebook_dim, dac_latent, dac_hidden, dac_n_up;
+    int32_t dac_up[8];          /* upsampling strides, e.g. 8,8,4,2 */
 } ptts_config;
 
 typedef struct ptts_engine ptts_engine;
@@ -100,6 +103,12 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
                  const float* enc_states, const int32_t* attention_mask, const int64_t* prompt_ids,
                  const int32_t* prompt_mask, const int64_t* pattern, int64_t* raw_ids, int32_t start_len,
                  void* stream);
+
+/* ---- codec: DACModel.decode (dac_wrapper/modeling_dac.py:98-134) = quantizer.from_codes + DAC.decode.
+ *      codes [B][K][F] int64 (every id < codebook_size), out [B][F * hop] fp32 waveform.  Conv stack =
+ *      implicit-GEMM MFMA kernels with fused Snake / bias / residual / tanh (csrc/conv.hip).  The first
+ *      call (and any call needing a larger workspace) allocates two ping-pong activation buffers. ---- */
+int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, float* out, void* stream);
 
 /* Sampling parameters of the third-party GenerationMixin step the reference calls at
  * modeling_parler_tts.py:2582 (greedy) / :2608 (sample).  */

@@ -124,9 +124,26 @@ def run_case(name, cfg, sd_kw, B, T, P, L, seed_in, ragged=False, pass_prompt_ma
     return r
 
 
+def dac_cases():
+    tiny, mini = tiny_config(), mini_v01_config()
+    # ---- codec decode vs the installed transformers DacModel (structural oracle)
+    for name, cfg, seed, B, Fr in (("dac_tiny", tiny, 11, 2, 7), ("dac_mini", mini, 21, 1, 6)):
+        sd = synthetic_state_dict(cfg, seed=seed, parts=("audio_encoder",))
+        hf = ref_shim.build_hf_dac(cfg, sd)
+        gg = torch.Generator().manual_seed(5)
+        codes = torch.randint(0, cfg.audio_encoder.codebook_size, (B, cfg.audio_encoder.num_codebooks, Fr), generator=gg)
+        with torch.no_grad():
+            z = hf.quantizer.from_codes(codes)[0]
+            wav = hf.decoder(z)
+        save(name, codes=codes, latent=z, wav=wav, seed=seed)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-dac" in sys.argv:
+        dac_cases()
+        return
     ref = ref_shim.load_reference()
 
     # ---- (1) integer path: delay masks straight from the reference functions (M:68-139)
@@ -166,15 +183,7 @@ def main():
     run_case("mini_greedy_ragged", mini, kwm, B=2, T=12, P=6, L=20, seed_in=201, ragged=True, record=4, min_margin=1e-3)
 
     # ---- (9) codec decode vs the installed transformers DacModel (structural oracle)
-    for name, cfg, seed, B, Fr in (("dac_tiny", tiny, 11, 2, 7), ("dac_mini", mini, 21, 1, 6)):
-        sd = synthetic_state_dict(cfg, seed=seed, parts=("audio_encoder",))
-        hf = ref_shim.build_hf_dac(cfg, sd)
-        gg = torch.Generator().manual_seed(5)
-        codes = torch.randint(0, cfg.audio_encoder.codebook_size, (B, cfg.audio_encoder.num_codebooks, Fr), generator=gg)
-        with torch.no_grad():
-            z = hf.quantizer.from_codes(codes)[0]
-            wav = hf.decoder(z)
-        save(name, codes=codes, latent=z, wav=wav, seed=seed)
+    dac_cases()
 
 
 if __name__ == "__main__":

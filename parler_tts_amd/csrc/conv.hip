@@ -1,0 +1,228 @@
+// DAC decoder convolutions as implicit GEMM on MFMA (gfx950), channels-last activations.
+//
+// Reference arithmetic: DACModel.decode (dac_wrapper/modeling_dac.py:98-134) -> descript DAC decoder;
+// structure per HF models/dac/modeling_dac.py:86-100 (Snake), 175-210 (residual unit), 236-266 (decoder
+// block), 407-442 (decoder):  conv7 -> R x [snake, convT(k=2s, stride s, pad s/2), 3 x {snake, conv7(dil),
+// snake, conv1, +x}] -> snake -> conv7 -> tanh.
+//
+// One kernel covers every layer:
+//     out[b][u][n] = epi( bias[n % Cout] + sum_tap sum_ci  A(in[b][u + tap*tstep + toff][ci]) * W[tap][n][ci] )
+//   Conv1d          : taps = k, tstep = dilation, toff = -pad, n = co, output row u
+//   ConvTranspose1d : a stride-s transposed conv with kernel 2s and padding s/2 is s interleaved 2-tap
+//                     convolutions (output phase r = (t + pad) mod s uses taps r and r+s):
+//                     taps = 2, tstep = -1, toff = 0, n = r*Cout + co, output time t = s*u - pad + r,
+//                     u in [0, Tin]; W[tap][r*Cout+co][ci] = w[ci][co][r + tap*s] (repacked at load)
+//   A() = Snake  x + sin^2(alpha x) / (alpha + 1e-9)  applied ONCE per staged input element (or identity)
+//   epi  = + residual (same shape as out) | tanh
+//
+// Tiling: workgroup = TM(128) time rows x TN(64|96) outputs of one utterance, 4 waves (one per SIMD), each
+// wave 32 rows x TN; per 16-channel chunk the input window (TM + halo rows, Snake applied) and the
+// weights of all taps are staged in LDS; fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain:
+// the waveform must match the CPU reference to 1e-4 rms, which rules out plain bf16 operands).
+#include "ptts_common.h"
+#include "conv.h"
+
+namespace {
+
+constexpr int TM = 128;      // time rows per workgroup
+constexpr int KC = 16;       // input channels per staged chunk
+constexpr int LDA = KC + 4;  // padded row strides (floats)
+constexpr int MAX_TAPS = 7;
+
+__device__ inline float snake_f(float x, float alpha, float inv) {
+    const float s = sinf(alpha * x);
+    return x + inv * (s * s);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = TN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n0 = blockIdx.x * TN;
+    const int u0 = blockIdx.y * TM;
+    const int b = blockIdx.z;
+    // window of input rows touched by this tile
+    const int lo = a.tstep >= 0 ? a.toff : a.toff + (a.taps - 1) * a.tstep;
+    const int hi = a.tstep >= 0 ? a.toff + (a.taps - 1) * a.tstep : a.toff;
+    const int win = TM + (hi - lo);
+    float* xs = reinterpret_cast<float*>(smem);                 // [win][LDA]
+    float* ws = xs + (size_t)win * LDA;                         // [taps][TN][LDA]
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = {0, 0, 0, 0};
+
+    const float* inb = a.in + (size_t)b * a.Tin * a.Cin;
+    for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+        // ---- stage the input window (Snake applied once per element) ----
+        for (int i = tid; i < win * (KC / 4); i += 256) {
+            const int r = i / (KC / 4), q = i % (KC / 4);
+            const int t = u0 + lo + r;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (t >= 0 && t < a.Tin) {
+                v = *reinterpret_cast<const float4*>(inb + (size_t)t * a.Cin + c0 + 4 * q);
+                if (a.alpha) {
+                    const float4 al = *reinterpret_cast<const float4*>(a.alpha + c0 + 4 * q);
+                    v.x = snake_f(v.x, al.x, 1.0f / (al.x + 1e-9f));
+                    v.y = snake_f(v.y, al.y, 1.0f / (al.y + 1e-9f));
+                    v.z = snake_f(v.z, al.z, 1.0f / (al.z + 1e-9f));
+                    v.w = snake_f(v.w, al.w, 1.0f / (al.w + 1e-9f));
+                }
+            }
+            *reinterpret_cast<float4*>(xs + (size_t)r * LDA + 4 * q) = v;
+        }
+        // ---- stage the weights of every tap for this channel chunk: W[tap][n][ci] ----
+        for (int i = tid; i < a.taps * TN * (KC / 4); i += 256) {
+            const int q = i % (KC / 4), n = (i / (KC / 4)) % TN, tap = i / ((KC / 4) * TN);
+            float4 v = make_float4(0, 0, 0, 0);
+            if (n0 + n < a.N)
+                v = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.N + n0 + n) * a.Cin + c0 + 4 * q);
+            *reinterpret_cast<float4*>(ws + ((size_t)tap * TN + n) * LDA + 4 * q) = v;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < a.taps; ++tap) {
+            const int roff = tap * a.tstep + a.toff - lo;        // window row of output row 0 for this tap
+            const float* xa = xs + (size_t)(w * 32 + roff + (lane & 15)) * LDA + (lane >> 4);
+            const float* wb = ws + ((size_t)tap * TN + (lane & 15)) * LDA + (lane >> 4);
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 4) {
+                const float a0 = xa[kk], a1 = xa[16 * LDA + kk];
+                float bf[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[j] = wb[(size_t)j * 16 * LDA + kk];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    // weights as the A operand (rows = outputs), activations as B (cols = time):
+                    // D[n = 4*(l>>4)+r][t = l&15] -> a lane owns 4 consecutive outputs of one time row
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], a0, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], a1, acc[1][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual, tanh; channels-last stores of 4 consecutive outputs ----
+    float* outb = a.out + (size_t)b * a.Tout * a.Cout;
+    const float* resb = a.res ? a.res + (size_t)b * a.Tout * a.Cout : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = u0 + w * 32 + i * 16 + (lane & 15);
+        if (u >= a.U) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + 4 * (lane >> 4);
+            if (n >= a.N) continue;
+            int t, co;
+            if (a.stride == 1) { t = u; co = n; }
+            else { const int r = n / a.Cout; co = n - r * a.Cout; t = a.stride * u - a.pad_t + r; }
+            if (t < 0 || t >= a.Tout) continue;
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + (co + e < a.Cout ? a.bias[co + e] : 0.f);
+            float* o = outb + (size_t)t * a.Cout + co;
+            if (co + 3 < a.Cout) {
+                if (resb) {
+                    const float4 rv = *reinterpret_cast<const float4*>(resb + (size_t)t * a.Cout + co);
+                    y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w;
+                }
+                if (a.act_out == 1) { y[0] = tanhf(y[0]); y[1] = tanhf(y[1]); y[2] = tanhf(y[2]); y[3] = tanhf(y[3]); }
+                *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+                for (int e = 0; e < 4 && co + e < a.Cout; ++e) {
+                    float v = y[e];
+                    if (resb) v += resb[(size_t)t * a.Cout + co + e];
+                    if (a.act_out == 1) v = tanhf(v);
+                    o[e] = v;
+                }
+            }
+        }
+    }
+}
+
+// z[b][f][c] = sum_k table[k][codes[b][k][f]][c]   (left to right over codebooks, as from_codes adds them)
+__global__ void dac_latent_kernel(const long long* codes, const float* table, float* z, int K, int F, int C, int ncodes) {
+    const int f = blockIdx.x, b = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const long long code = codes[((size_t)b * K + k) * F + f];
+            s = s + table[((size_t)k * ncodes + code) * C + c];
+        }
+        z[((size_t)b * F + f) * C + c] = s;
+    }
+}
+
+// table[k][code][c] = bias_k[c] + sum_d out_proj_k[c][d] * codebook_k[code][d]   (1x1 conv of the embedding)
+__global__ void dac_table_kernel(const float* codebook, const float* proj_w, const float* proj_b, float* table, int ncodes,
+                                 int dim, int C) {
+    const int code = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int d = 0; d < dim; ++d) s = fmaf(proj_w[(size_t)c * dim + d], codebook[(size_t)code * dim + d], s);
+        table[(size_t)code * C + c] = s + proj_b[c];
+    }
+}
+
+// Conv1d weight [Cout][Cin][k] -> [k][Npad][Cin];  ConvTranspose1d weight [Cin][Cout][2s] -> [2][s*Cout][Cin]
+__global__ void conv_pack_kernel(const float* w, float* out, int Cout, int Cin, int k, int transposed, int s, int N) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)(transposed ? 2 : k) * N * Cin;
+    if (idx >= total) return;
+    const int ci = (int)(idx % Cin);
+    const int n = (int)((idx / Cin) % N);
+    const int tap = (int)(idx / ((size_t)Cin * N));
+    float v = 0.f;
+    if (!transposed) {
+        if (n < Cout) v = w[((size_t)n * Cin + ci) * k + tap];
+    } else {
+        const int r = n / Cout, co = n % Cout;
+        if (r < s) v = w[((size_t)ci * Cout + co) * (2 * s) + r + tap * s];
+    }
+    out[idx] = v;
+}
+
+}  // namespace
+
+hipError_t conv_init() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
+    if (a.taps > MAX_TAPS || a.Cin % KC != 0) return hipErrorInvalidValue;
+    const int lo = a.tstep >= 0 ? a.toff : a.toff + (a.taps - 1) * a.tstep;
+    const int hi = a.tstep >= 0 ? a.toff + (a.taps - 1) * a.tstep : a.toff;
+    const int win = TM + (hi - lo);
+    const int TN = (a.N % 64 == 0) ? 64 : 96;
+    const size_t lds = ((size_t)win * LDA + (size_t)a.taps * TN * LDA) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid((a.N + TN - 1) / TN, (a.U + TM - 1) / TM, a.B);
+    if (TN == 64) hipLaunchKernelGGL(conv_kernel<64>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(conv_kernel<96>, grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t dac_latent_launch(const long long* codes, const float* table, float* z, int B, int K, int F, int C, int ncodes,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(dac_latent_kernel, dim3(F, B), dim3(256), 0, s, codes, table, z, K, F, C, ncodes);
+    return hipGetLastError();
+}
+
+hipError_t dac_table_launch(const float* codebook, const float* proj_w, const float* proj_b, float* table, int ncodes, int dim,
+                            int C, hipStream_t s) {
+    hipLaunchKernelGGL(dac_table_kernel, dim3(ncodes), dim3(256), 0, s, codebook, proj_w, proj_b, table, ncodes, dim, C);
+    return hipGetLastError();
+}
+
+hipError_t conv_pack_launch(const float* w, float* out, int Cout, int Cin, int k, int transposed, int stride, int N,
+                            hipStream_t s) {
+    size_t total = (size_t)(transposed ? 2 : k) * N * Cin;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, Cout, Cin, k,
+                       transposed, stride, N);
+    return hipGetLastError();
+}

@@ -11,10 +11,12 @@
 #include <map>
 #include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/parler_tts_hip.h"
 #include "attn.h"
+#include "conv.h"
 #include "gemm.h"
 #include "misc.h"
 
@@ -59,6 +61,12 @@ struct T5Layer {
     float *ln0 = nullptr, *ln1 = nullptr;
 };
 
+struct ConvLayer {
+    float *w = nullptr, *bias = nullptr, *alpha = nullptr;   // packed weight, bias, Snake alpha of the INPUT
+    int Cin = 0, Cout = 0, k = 1, dil = 1, stride = 1;
+    bool transposed = false, have_w = false, have_b = false, have_a = false, needs_alpha = false;
+};
+
 struct EventPair {
     hipEvent_t a, b;
     double bytes;
@@ -98,6 +106,13 @@ struct ptts_engine {
     long long* force = nullptr;
     bool use_force = false;
     StepState* state = nullptr;
+    // DAC decoder (codec): conv0, per block {convT, 3 x (conv7, conv1)}, final conv
+    std::vector<ConvLayer> dac;
+    std::vector<float*> dac_codebook, dac_proj_w, dac_proj_b;
+    float* dac_table = nullptr;
+    bool dac_table_ready = false;
+    float *dac_buf0 = nullptr, *dac_buf1 = nullptr;
+    size_t dac_buf_floats = 0;
     // T5 workspaces
     float *t5_x = nullptr, *t5_qkv = nullptr;
     void *t5_afrag = nullptr, *t5_ffrag = nullptr;
@@ -355,6 +370,97 @@ int capture_step_graph(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
     return PTTS_OK;
 }
 
+int dac_layer_index(const ptts_engine* e, int n, int r, int sub) {
+    // decoder.model.{n}: n=0 conv0; n=1..R block n-1 {block.1 = convT, block.{2,3,4}.block.{1,3} = conv7/conv1}; n=R+2 final
+    const int R = e->cfg.dac_n_up;
+    if (n == 0) return 0;
+    if (n >= 1 && n <= R) {
+        const int base = 1 + (n - 1) * 7;
+        if (r == 1) return base;                       // transposed conv
+        if (r >= 2 && r <= 4) return base + 1 + (r - 2) * 2 + (sub == 3 ? 1 : 0);
+        return -1;
+    }
+    if (n == R + 2) return (int)e->dac.size() - 1;
+    return -1;
+}
+
+// returns 0 ok, 1 unknown name, <0 error
+int load_dac_tensor(ptts_engine* e, const std::string& n, const float* data, const int64_t* shape, int ndim, hipStream_t s) {
+    const ptts_config& c = e->cfg;
+    int idx = 0;
+    std::string rest;
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    if (parse_idx(n, "quantizer.quantizers.", &idx, &rest)) {
+        if (idx < 0 || idx >= c.codebooks) return fail(PTTS_E_INVALID, "quantizer %d out of range", idx);
+        float** dst = nullptr;
+        size_t want = 0;
+        if (rest == "codebook.weight") { dst = &e->dac_codebook[idx]; want = (size_t)c.dac_codebook_size * c.dac_codebook_dim; }
+        else if (rest == "out_proj.weight") { dst = &e->dac_proj_w[idx]; want = (size_t)c.dac_latent * c.dac_codebook_dim; }
+        else if (rest == "out_proj.bias") { dst = &e->dac_proj_b[idx]; want = (size_t)c.dac_latent; }
+        else if (rest.compare(0, 8, "in_proj.") == 0) return PTTS_OK;   // encode side, unused
+        else return 1;
+        if (numel != want) return fail(PTTS_E_INVALID, "quantizer tensor size %zu != %zu", numel, want);
+        if (!*dst) PTTS_TRY(dev_alloc(e, (void**)dst, want * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(*dst, data, want * sizeof(float), hipMemcpyDeviceToDevice, s));
+        e->dac_table_ready = false;
+        return PTTS_OK;
+    }
+    if (n.compare(0, 8, "encoder.") == 0) return PTTS_OK;   // DAC encoder: not on the decode path
+    if (!parse_idx(n, "decoder.model.", &idx, &rest)) return 1;
+    const int R = c.dac_n_up;
+    int r = -1, sub = -1;
+    std::string leaf = rest;
+    if (idx >= 1 && idx <= R) {
+        std::string r2;
+        if (!parse_idx(rest, "block.", &r, &r2)) return 1;
+        leaf = r2;
+        if (r >= 2) {
+            std::string r3;
+            if (!parse_idx(r2, "block.", &sub, &r3)) return 1;
+            leaf = r3;
+        }
+    }
+    // Snake alphas belong to the layer that CONSUMES them
+    if (leaf == "alpha") {
+        int li = -1;
+        if (idx >= 1 && idx <= R) {
+            if (r == 0) li = dac_layer_index(e, idx, 1, 0);
+            else if (r >= 2 && (sub == 0 || sub == 2)) li = dac_layer_index(e, idx, r, sub + 1);
+        } else if (idx == R + 1) li = (int)e->dac.size() - 1;
+        if (li < 0) return 1;
+        ConvLayer& L = e->dac[li];
+        if (numel != (size_t)L.Cin) return fail(PTTS_E_INVALID, "alpha size %zu != %d", numel, L.Cin);
+        if (!L.alpha) PTTS_TRY(dev_alloc(e, (void**)&L.alpha, numel * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(L.alpha, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+        L.have_a = true;
+        return PTTS_OK;
+    }
+    const int li = (idx >= 1 && idx <= R) ? dac_layer_index(e, idx, r, sub) : dac_layer_index(e, idx, 0, 0);
+    if (li < 0) return 1;
+    ConvLayer& L = e->dac[li];
+    if (leaf == "bias") {
+        if (numel != (size_t)L.Cout) return fail(PTTS_E_INVALID, "bias size %zu != %d", numel, L.Cout);
+        if (!L.bias) PTTS_TRY(dev_alloc(e, (void**)&L.bias, numel * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(L.bias, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+        L.have_b = true;
+        return PTTS_OK;
+    }
+    if (leaf == "weight") {
+        if (ndim != 3) return fail(PTTS_E_INVALID, "conv weight must be 3-D");
+        const bool ok = L.transposed ? (shape[0] == L.Cin && shape[1] == L.Cout && shape[2] == L.k)
+                                     : (shape[0] == L.Cout && shape[1] == L.Cin && shape[2] == L.k);
+        if (!ok) return fail(PTTS_E_INVALID, "conv weight shape mismatch for decoder.model.%d", idx);
+        const int N = L.transposed ? L.stride * L.Cout : L.Cout;
+        const int taps = L.transposed ? 2 : L.k;
+        if (!L.w) PTTS_TRY(dev_alloc(e, (void**)&L.w, (size_t)taps * N * L.Cin * sizeof(float)));
+        HIP_TRY(conv_pack_launch(data, L.w, L.Cout, L.Cin, L.k, L.transposed ? 1 : 0, L.stride, N, s));
+        L.have_w = true;
+        return PTTS_OK;
+    }
+    return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -380,6 +486,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PTTS_E_HIP, "no HIP device visible");
     HIP_TRY(gemm_init());
     HIP_TRY(attn_init());
+    HIP_TRY(conv_init());
     ptts_engine* e = new ptts_engine();
     e->cfg = *cfg;
     e->dt = cfg->dtype;
@@ -388,6 +495,34 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->layers.resize(cfg->layers);
     e->t5.resize(cfg->t5_layers > 0 ? cfg->t5_layers : 0);
     e->no_graph = getenv("PTTS_NO_GRAPH") != nullptr;
+    if (cfg->dac_hidden > 0) {
+        if (cfg->dac_n_up <= 0 || cfg->dac_n_up > 8 || cfg->dac_hidden % (16 << cfg->dac_n_up) != 0 || cfg->dac_latent % 16 != 0) {
+            delete e;
+            return fail(PTTS_E_UNSUPPORTED, "codec dims: latent and hidden / 2^n_up must be multiples of 16");
+        }
+        ConvLayer c0; c0.Cin = cfg->dac_latent; c0.Cout = cfg->dac_hidden; c0.k = 7;
+        e->dac.push_back(c0);
+        int cin = cfg->dac_hidden;
+        for (int i = 0; i < cfg->dac_n_up; ++i) {
+            const int st = cfg->dac_up[i];
+            if (st < 2 || st % 2 != 0) { delete e; return fail(PTTS_E_UNSUPPORTED, "codec strides must be even"); }
+            ConvLayer t; t.Cin = cin; t.Cout = cin / 2; t.k = 2 * st; t.stride = st; t.transposed = true; t.needs_alpha = true;
+            e->dac.push_back(t);
+            const int dils[3] = {1, 3, 9};
+            for (int r = 0; r < 3; ++r) {
+                ConvLayer a7; a7.Cin = cin / 2; a7.Cout = cin / 2; a7.k = 7; a7.dil = dils[r]; a7.needs_alpha = true;
+                ConvLayer a1; a1.Cin = cin / 2; a1.Cout = cin / 2; a1.k = 1; a1.needs_alpha = true;
+                e->dac.push_back(a7);
+                e->dac.push_back(a1);
+            }
+            cin /= 2;
+        }
+        ConvLayer fin; fin.Cin = cin; fin.Cout = 1; fin.k = 7; fin.needs_alpha = true;
+        e->dac.push_back(fin);
+        e->dac_codebook.assign(cfg->codebooks, nullptr);
+        e->dac_proj_w.assign(cfg->codebooks, nullptr);
+        e->dac_proj_b.assign(cfg->codebooks, nullptr);
+    }
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming) != hipSuccess) {
@@ -453,6 +588,8 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
 int ptts_destroy(ptts_engine* e) {
     if (!e) return PTTS_OK;
     drop_graph(e);
+    if (e->dac_buf0) (void)hipFree(e->dac_buf0);
+    if (e->dac_buf1) (void)hipFree(e->dac_buf1);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
@@ -531,8 +668,12 @@ int ptts_load_tensor(ptts_engine* e, const char* cname, const float* data, const
         else if (rest == "layer.1.DenseReluDense.wi.weight") rc = load_packed(e, &w.wi, ff, d, 0, 1, data, shape, ndim, ff, s);
         else if (rest == "layer.1.DenseReluDense.wo.weight") rc = load_packed(e, &w.wo, d, ff, 0, 1, data, shape, ndim, d, s);
         else known = false;
-    } else if (name.compare(0, 14, "audio_encoder.") == 0 || name == "text_encoder.encoder.embed_tokens.weight") {
-        return PTTS_OK;  // codec weights are not consumed by this library yet; tied T5 embedding alias
+    } else if (name.compare(0, 20, "audio_encoder.model.") == 0) {
+        if (e->dac.empty()) return PTTS_OK;   // engine created without the codec
+        rc = load_dac_tensor(e, name.substr(20), data, shape, ndim, s);
+        if (rc == 1) known = false;
+    } else if (name == "text_encoder.encoder.embed_tokens.weight") {
+        return PTTS_OK;  // tied T5 embedding alias
     } else known = false;
     if (!known) return fail(PTTS_E_INVALID, "unknown tensor name '%s'", cname);
     if (rc == PTTS_OK) e->loaded.insert(name);
@@ -778,6 +919,83 @@ int ptts_set_forced_tokens(ptts_engine* e, const int64_t* tokens_host, int32_t r
     HIP_TRY(hipMemcpy(e->force, tokens_host, sizeof(long long) * rows, hipMemcpyHostToDevice));
     e->use_force = true;
     return PTTS_OK;
+}
+
+int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, float* out, void* stream) {
+    if (!e || !codes || !out) return fail(PTTS_E_INVALID, "null argument");
+    if (e->dac.empty()) return fail(PTTS_E_STATE, "engine was created without the codec (dac_hidden = 0)");
+    if (B <= 0 || F <= 0) return fail(PTTS_E_INVALID, "B=%d F=%d", B, F);
+    const ptts_config& c = e->cfg;
+    for (size_t i = 0; i < e->dac.size(); ++i) {
+        const ConvLayer& L = e->dac[i];
+        if (!L.have_w || !L.have_b || (L.needs_alpha && !L.have_a)) return fail(PTTS_E_STATE, "codec layer %zu is missing tensors", i);
+    }
+    for (int k = 0; k < c.codebooks; ++k)
+        if (!e->dac_codebook[k] || !e->dac_proj_w[k] || !e->dac_proj_b[k]) return fail(PTTS_E_STATE, "quantizer %d is missing tensors", k);
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
+    if (!e->dac_table_ready) {   // fold codebook lookup + 1x1 out_proj (+bias) into one table per codebook
+        const size_t per = (size_t)c.dac_codebook_size * c.dac_latent;
+        if (!e->dac_table) PTTS_TRY(dev_alloc(e, (void**)&e->dac_table, per * c.codebooks * sizeof(float)));
+        for (int k = 0; k < c.codebooks; ++k)
+            HIP_TRY(dac_table_launch(e->dac_codebook[k], e->dac_proj_w[k], e->dac_proj_b[k], e->dac_table + per * k,
+                                     c.dac_codebook_size, c.dac_codebook_dim, c.dac_latent, s));
+        e->dac_table_ready = true;
+    }
+    // largest activation of the stack, per utterance (channels-last floats)
+    size_t per_utt = (size_t)F * (c.dac_latent > c.dac_hidden ? c.dac_latent : c.dac_hidden);
+    {
+        size_t T = F; int ch = c.dac_hidden;
+        for (int i = 0; i < c.dac_n_up; ++i) { T *= c.dac_up[i]; ch /= 2; if (T * ch > per_utt) per_utt = T * ch; }
+    }
+    const size_t budget = (size_t)12 << 30;   // bytes per ping-pong buffer
+    int chunk = (int)(budget / (per_utt * sizeof(float)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > B) chunk = B;
+    const size_t need = per_utt * chunk;
+    if (need > e->dac_buf_floats) {   // one-off (re)allocation of the codec workspace; cached across calls
+        HIP_TRY(hipStreamSynchronize(s));
+        if (e->dac_buf0) (void)hipFree(e->dac_buf0);
+        if (e->dac_buf1) (void)hipFree(e->dac_buf1);
+        e->dac_buf0 = e->dac_buf1 = nullptr; e->dac_buf_floats = 0;
+        if (hipMalloc((void**)&e->dac_buf0, need * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&e->dac_buf1, need * sizeof(float)) != hipSuccess)
+            return fail(PTTS_E_NOMEM, "codec workspace of 2 x %zu bytes", need * sizeof(float));
+        e->dac_buf_floats = need;
+    }
+    int hop = 1;
+    for (int i = 0; i < c.dac_n_up; ++i) hop *= c.dac_up[i];
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        float* cur = e->dac_buf0;
+        float* nxt = e->dac_buf1;
+        HIP_TRY(dac_latent_launch((const long long*)codes + (size_t)b0 * c.codebooks * F, e->dac_table, cur, nb, c.codebooks, F,
+                                  c.dac_latent, c.dac_codebook_size, s));
+        int T = F;
+        for (size_t i = 0; i < e->dac.size(); ++i) {
+            const ConvLayer& L = e->dac[i];
+            const bool last = i + 1 == e->dac.size();
+            ConvArgs a;
+            a.in = cur; a.w = L.w; a.bias = L.bias; a.alpha = L.needs_alpha ? L.alpha : nullptr;
+            a.B = nb; a.Tin = T; a.Cin = L.Cin; a.Cout = L.Cout;
+            if (L.transposed) {
+                a.Tout = T * L.stride; a.N = L.stride * L.Cout; a.U = T + 1; a.taps = 2; a.tstep = -1; a.toff = 0;
+                a.stride = L.stride; a.pad_t = L.stride / 2; a.out = nxt;
+            } else {
+                a.Tout = T; a.N = L.Cout; a.U = T; a.taps = L.k; a.tstep = L.dil; a.toff = -((L.k - 1) * L.dil) / 2;
+                // residual unit: conv7 writes h to the other buffer, conv1 adds into the unit's input in place
+                const bool is_res_conv1 = (L.k == 1);
+                if (is_res_conv1) { a.out = nxt; a.res = nxt; }
+                else a.out = last ? out + (size_t)b0 * F * hop : nxt;
+                if (last) a.act_out = 1;
+            }
+            HIP_TRY(conv_launch(a, s));
+            if (L.transposed) { T = a.Tout; std::swap(cur, nxt); }
+            else if (L.k == 1) { std::swap(cur, nxt); }   // result is in nxt (= the unit's input buffer)
+            else if (!last) { std::swap(cur, nxt); }       // conv7 / conv0 result becomes current
+        }
+    }
+    return leave_stream(e, stream, s);
 }
 
 int ptts_debug_stop_after(ptts_engine* e, int32_t n_kernels) {

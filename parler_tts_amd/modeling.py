@@ -64,13 +64,18 @@ class HipEngine:
     """Owns one ``ptts_engine`` handle (weights packed in HBM, KV pools, workspaces)."""
 
     def __init__(self, cfg: ParlerTTSConfig, state_dict: Dict[str, torch.Tensor], dtype: str, device: torch.device,
-                 max_batch: int, max_desc_len: int, max_prompt_len: int, max_length: int, with_t5: bool = True):
+                 max_batch: int, max_desc_len: int, max_prompt_len: int, max_length: int, with_t5: bool = True,
+                 codec_only: bool = False):
         self.lib = _hip.load_library()
         if device.type != "cuda":
             raise RuntimeError("the HIP engine needs a ROCm device (torch device type 'cuda')")
         self.device = device
         self.dtype = dtype
         d, t5 = cfg.decoder, cfg.text_encoder
+        self.codec_only = codec_only
+        self.has_codec = any(k.startswith("audio_encoder.model.decoder.") for k in state_dict)
+        if codec_only:
+            with_t5 = False
         c = _hip.PttsConfig()
         c.abi_version = _hip.ABI_VERSION
         c.dtype = _hip.DTYPE_BF16 if dtype == "bf16" else _hip.DTYPE_F32
@@ -84,6 +89,15 @@ class HipEngine:
         c.t5_act = _ACT[t5.dense_act_fn]
         c.t5_eps = t5.layer_norm_epsilon
         c.max_batch, c.max_desc_len, c.max_prompt_len, c.max_length = max_batch, max_desc_len, max_prompt_len, max_length
+        if codec_only:   # a placeholder decoder: only ptts_dac_decode will be called on this handle
+            c.hidden, c.layers, c.heads, c.ffn, c.vocab, c.max_positions = 64, 0, 1, 32, 16, 64
+            c.prompt_vocab, c.enc_hidden, c.max_batch, c.max_desc_len, c.max_prompt_len, c.max_length = 16, 32, 1, 1, 0, 2
+        if self.has_codec:
+            a = cfg.audio_encoder
+            c.dac_codebook_size, c.dac_codebook_dim, c.dac_latent = a.codebook_size, a.codebook_dim, a.latent_dim
+            c.dac_hidden, c.dac_n_up = a.decoder_hidden_size, len(a.upsampling_ratios)
+            for i, r in enumerate(a.upsampling_ratios):
+                c.dac_up[i] = int(r)
         self.limits = (max_batch, max_desc_len, max_prompt_len, max_length)
         self.cfg = cfg
         self.handle = C.c_void_p()
@@ -99,7 +113,9 @@ class HipEngine:
         n = 0
         staged = []   # the fp32 staging copies must outlive the asynchronous pack kernels that read them
         for name, t in sd.items():
-            if name.startswith("audio_encoder."):
+            if name.startswith("audio_encoder.") and not self.has_codec:
+                continue
+            if self.codec_only and not name.startswith("audio_encoder."):
                 continue
             if name.startswith("text_encoder.") and not with_t5:
                 continue
@@ -114,7 +130,8 @@ class HipEngine:
                 n = 0
         torch.cuda.synchronize(self.device)
         staged.clear()
-        _hip.check(self.lib.ptts_weights_ready(self.handle))
+        if not self.codec_only:
+            _hip.check(self.lib.ptts_weights_ready(self.handle))
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
@@ -138,6 +155,16 @@ class HipEngine:
         out = torch.empty(B, T, t5.d_model, device=self.device, dtype=torch.float32)
         _hip.check(self.lib.ptts_t5_encode(self.handle, B, T, _ptr(ids), _ptr(mask), _ptr(table), _ptr(out), _stream()))
         torch.cuda.current_stream().synchronize()  # `table`/`ids` are temporaries
+        return out
+
+    def dac_decode(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes [B, K, F] int64 -> waveform [B, F * hop] fp32 (ptts_dac_decode)."""
+        B, K, F = codes.shape
+        hop = self.cfg.audio_encoder.hop_length
+        codes = codes.to(self.device, torch.int64).contiguous()
+        out = torch.empty(B, F * hop, device=self.device, dtype=torch.float32)
+        _hip.check(self.lib.ptts_dac_decode(self.handle, B, F, _ptr(codes), _ptr(out), _stream()))
+        torch.cuda.current_stream().synchronize()   # `codes` may be a temporary
         return out
 
     def prefill(self, B, B_eff, enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, start_len):
@@ -209,63 +236,53 @@ def _hipMemcpyDtoD(dst: int, src: int, nbytes: int) -> int:
 
 class DACModel:
     """Codec wrapper with the reference's ``decode`` contract (dac_wrapper/modeling_dac.py:98-134):
-    ``audio_codes [1, B, K, F]`` -> ``audio_values [B, 1, F * hop]``.
-
-    STATUS (round 1): the conv stack runs as stock PyTorch-ROCm ops on the GPU (fp32, MIOpen/rocBLAS);
-    the hand-written MFMA implicit-GEMM kernels are the next SURVEY section-8 row to land.  It never runs on
-    the CPU and never touches the oracle."""
+    ``audio_codes [1, B, K, F]`` -> ``audio_values [B, 1, F * hop]``.  The arithmetic (quantizer.from_codes +
+    the DAC decoder conv stack) runs in ``ptts_dac_decode`` (csrc/conv.hip: implicit-GEMM MFMA kernels with
+    fused Snake / bias / residual / tanh).  ``encode`` (audio prompts, training pre-processing) is outside
+    the accelerated path."""
 
     config_class = DACConfig
 
-    def __init__(self, config: DACConfig, state_dict: Dict[str, torch.Tensor], device: torch.device):
-        self.config = config
-        self.device = device
-        p = "audio_encoder.model."
-        self.w = {k[len(p):]: v.to(device=device, dtype=torch.float32).contiguous()
-                  for k, v in state_dict.items() if k.startswith(p)}
-        if not self.w:
-            raise RuntimeError("state dict holds no audio_encoder.model.* tensors")
+    def __init__(self, config, state_dict: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0", engine_provider=None):
+        # `config`: DACConfig, or a full ParlerTTSConfig when built stand-alone from a state dict
+        self.device = torch.device(device)
+        self._provider = engine_provider
+        self._own = None
+        if isinstance(config, ParlerTTSConfig):
+            self.config, full = config.audio_encoder, config
+        else:
+            self.config, full = config, None
+        if engine_provider is None:
+            if state_dict is None:
+                raise RuntimeError("DACModel needs a state dict (audio_encoder.model.* tensors) or an engine")
+            if full is None:
+                from .configuration import ParlerTTSDecoderConfig, T5EncoderConfig
+
+                full = ParlerTTSConfig.from_sub_models_config(
+                    T5EncoderConfig(), self.config, ParlerTTSDecoderConfig(num_codebooks=self.config.num_codebooks))
+            sd = {k: v for k, v in state_dict.items() if k.startswith("audio_encoder.")}
+            if not sd:
+                raise RuntimeError("state dict holds no audio_encoder.model.* tensors")
+            self._own = HipEngine(full, sd, "fp32", self.device, 1, 1, 0, 2, codec_only=True)
+
+    def _engine(self) -> HipEngine:
+        return self._own if self._own is not None else self._provider()
 
     @torch.no_grad()
     def decode(self, audio_codes, audio_scales=None, padding_mask=None, return_dict=None):
-        import torch.nn.functional as F
-
         if len(audio_codes) != 1:
             raise ValueError(f"Expected one frame, got {len(audio_codes)}")
-        codes = audio_codes.squeeze(0).to(self.device)
-        w, cfg = self.w, self.config
-        # bound the transient activations (96 ch x 512 samples per frame in the last block): a few
-        # utterances at a time for long clips
-        per_utt = codes.shape[-1] * cfg.hop_length * (cfg.decoder_hidden_size // 2 ** len(cfg.upsampling_ratios)) * 4
-        chunk = max(1, min(codes.shape[0], int(6e9 // max(per_utt * 6, 1))))
-        if chunk < codes.shape[0]:
-            outs = [self.decode(codes[i:i + chunk][None], None).audio_values for i in range(0, codes.shape[0], chunk)]
-            return ModelOutput(audio_values=torch.cat(outs, dim=0))
+        codes = audio_codes.squeeze(0)
+        if codes.dim() != 3:
+            raise ValueError("audio_codes must be [1, batch, codebooks, frames]")
+        wav = self._engine().dac_decode(codes)
+        return ModelOutput(audio_values=wav[:, None, :])
 
-        def snake(x, alpha):
-            return x + (alpha + 1e-9).reciprocal() * torch.sin(alpha * x).pow(2)
+    def encode(self, *a, **k):
+        raise NotImplementedError("DACModel.encode (audio prompts) is a SURVEY section-8(f) 'next' row")
 
-        z = 0.0
-        for k in range(codes.shape[1]):
-            e = F.embedding(codes[:, k, :], w[f"quantizer.quantizers.{k}.codebook.weight"]).transpose(1, 2)
-            z = z + F.conv1d(e, w[f"quantizer.quantizers.{k}.out_proj.weight"], w[f"quantizer.quantizers.{k}.out_proj.bias"])
-        x = F.conv1d(z, w["decoder.model.0.weight"], w["decoder.model.0.bias"], padding=3)
-        for n, stride in enumerate(cfg.upsampling_ratios, start=1):
-            b = f"decoder.model.{n}.block."
-            x = snake(x, w[b + "0.alpha"])
-            x = F.conv_transpose1d(x, w[b + "1.weight"], w[b + "1.bias"], stride=stride, padding=math.ceil(stride / 2))
-            for r, dil in zip((2, 3, 4), (1, 3, 9)):
-                u = f"{b}{r}.block."
-                y = F.conv1d(snake(x, w[u + "0.alpha"]), w[u + "1.weight"], w[u + "1.bias"], dilation=dil, padding=3 * dil)
-                y = F.conv1d(snake(y, w[u + "2.alpha"]), w[u + "3.weight"], w[u + "3.bias"])
-                crop = (x.shape[-1] - y.shape[-1]) // 2
-                if crop > 0:
-                    x = x[..., crop:-crop]
-                x = x + y
-        R = len(cfg.upsampling_ratios)
-        x = snake(x, w[f"decoder.model.{R + 1}.alpha"])
-        x = torch.tanh(F.conv1d(x, w[f"decoder.model.{R + 2}.weight"], w[f"decoder.model.{R + 2}.bias"], padding=3))
-        return ModelOutput(audio_values=x)
+    def forward(self, tensor):
+        raise ValueError("`DACModel.forward` not implemented yet")   # same message as the reference (D:136-137)
 
 
 class ParlerTTSForConditionalGeneration:
@@ -333,7 +350,9 @@ class ParlerTTSForConditionalGeneration:
     @property
     def audio_encoder(self) -> DACModel:
         if self._dac is None:
-            self._dac = DACModel(self.config.audio_encoder, self._sd, self.device)
+            if not any(k.startswith("audio_encoder.model.decoder.") for k in (self._sd or {})):
+                raise RuntimeError("this model was built without codec weights (audio_encoder.model.*)")
+            self._dac = DACModel(self.config.audio_encoder, device=self.device, engine_provider=self.engine)
         return self._dac
 
     def engine(self, B_eff: int = 1, T: int = 1, P: int = 0, L: int = 2) -> HipEngine:
