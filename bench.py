@@ -105,7 +105,6 @@ def main():
     ap.add_argument("--desc-len", type=int, default=40)
     ap.add_argument("--prompt-len", type=int, default=16)
     ap.add_argument("--profile-every", type=int, default=64)
-    ap.add_argument("--micro-batches", type=int, default=1, help="independent batch slices run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dac", action="store_true", help="stop at codec ids (diagnostic; not the headline)")
     args = ap.parse_args()
@@ -135,7 +134,6 @@ def main():
     sd = synthetic_state_dict(cfg, seed=1234, never_eos=True)
     model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=args.dtype, device=dev)
     model.profile_every = args.profile_every
-    model.micro_batches = args.micro_batches
     desc, prompt = synth_inputs(cfg, B, T, P, seed=1234 + rank)   # every rank its own utterances (weak scaling)
     desc, prompt = desc.to(dev), prompt.to(dev)
     amask = torch.ones(B, T, dtype=torch.long, device=dev)

@@ -46,7 +46,8 @@ template <> struct KVLoad<PF32> {
     }
 };
 
-template <typename P, typename OP>
+// SELF only names the instantiation (self- vs cross-attention launches show up separately in rocprof)
+template <typename P, typename OP, bool SELF>
 __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     typedef typename P::elem_t elem_t;
     typedef KVLoad<P> L;
@@ -273,13 +274,19 @@ hipError_t attn_init() {
 hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream) {
     size_t lds = ((size_t)a.s_cap + NWAVES * 64 + NWAVES + a.pool.max_blocks) * sizeof(float);
     dim3 grid(H, B), block(NWAVES * 64);
+#define PTTS_ATTN_LAUNCH(P_, O_)                                                                             \
+    do {                                                                                                     \
+        if (a.len_from_state) hipLaunchKernelGGL((attn_decode_kernel<P_, O_, true>), grid, block, lds, stream, a); \
+        else hipLaunchKernelGGL((attn_decode_kernel<P_, O_, false>), grid, block, lds, stream, a);            \
+    } while (0)
     if (cache_dtype == PTTS_BF16) {
-        if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_decode_kernel<PBF16, PBF16>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<PBF16, PF32>), grid, block, lds, stream, a);
+        if (out_dtype == PTTS_BF16) PTTS_ATTN_LAUNCH(PBF16, PBF16);
+        else PTTS_ATTN_LAUNCH(PBF16, PF32);
     } else {
-        if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_decode_kernel<PF32, PBF16>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<PF32, PF32>), grid, block, lds, stream, a);
+        if (out_dtype == PTTS_BF16) PTTS_ATTN_LAUNCH(PF32, PBF16);
+        else PTTS_ATTN_LAUNCH(PF32, PF32);
     }
+#undef PTTS_ATTN_LAUNCH
     return hipGetLastError();
 }
 

@@ -301,9 +301,6 @@ class ParlerTTSForConditionalGeneration:
         self.device = torch.device(device)
         self._sd = state_dict
         self._engine: Optional[HipEngine] = None
-        self._extra_engines = []      # engines 1.. of the micro-batch pipeline (engine 0 is self._engine)
-        self._streams = []
-        self.micro_batches = 1        # >1: split the batch, one engine + HIP stream per slice, run concurrently
         self._dac: Optional[DACModel] = None
         d = config.decoder
         self.generation_config = generation_config or GenerationConfig(
@@ -478,19 +475,12 @@ class ParlerTTSForConditionalGeneration:
         sp.top_k = int(gen.top_k or 0)
         sp.guidance_scale = float(gen.guidance_scale) if use_cfg else 1.0
         sp.seed = int(gen.seed if gen.seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        nmb = self.micro_batches if (self.micro_batches > 1 and streamer is None and not use_cfg
-                                     and B % self.micro_batches == 0) else 1
-        if nmb == 1:
-            eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len)
+        eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len)
         t_dec = _tick()
         # ---- the hot loop: state lives on the device, the host only polls for "all rows finished" ----
         remaining = L - start_len
         chunk = 1 if streamer is not None else 128
         L_out = L
-        if nmb > 1:
-            L_out = self._decode_micro_batched(nmb, B, T, P, L, enc, amask32, pids, pmask32, pattern, raw_ids,
-                                               start_len, sp, gen)
-            remaining = 0
         while remaining > 0:
             n = min(chunk, remaining)
             eng.decode_steps(n, sp, self.profile_every)
@@ -546,53 +536,6 @@ class ParlerTTSForConditionalGeneration:
         if gen.return_dict_in_generate:
             return ModelOutput(sequences=values)
         return values
-
-    def _decode_micro_batched(self, nmb, B, T, P, L, enc, amask32, pids, pmask32, pattern, raw_ids, start_len, sp, gen):
-        """Utterances are independent, so the batch is cut into `nmb` slices that run as separate
-        engines on separate HIP streams: one slice's latency-bound projection kernels overlap another
-        slice's bandwidth-bound attention kernels.  Same kernels, same per-row arithmetic."""
-        K = self.config.decoder.num_codebooks
-        Bs = B // nmb
-        engines = [self._engine] + self._extra_engines
-        while len(engines) < nmb:
-            e = HipEngine(self.config, self._sd, self.dtype, self.device, *self._engine.limits)
-            self._extra_engines.append(e)
-            engines.append(e)
-        while len(self._streams) < nmb:
-            self._streams.append(torch.cuda.Stream(device=self.device))
-        cur = torch.cuda.current_stream()
-        views = []
-        for i in range(nmb):
-            r0, r1 = i * Bs, (i + 1) * Bs
-            views.append(dict(
-                enc=enc[r0:r1].contiguous(), am=amask32[r0:r1].contiguous(),
-                pids=None if pids is None else pids[r0:r1].contiguous(),
-                pm=None if pmask32 is None else pmask32[r0:r1].contiguous(),
-                pat=pattern[r0 * K:r1 * K].contiguous(), raw=raw_ids[r0 * K:r1 * K].clone()))
-        for i in range(nmb):
-            self._streams[i].wait_stream(cur)
-            with torch.cuda.stream(self._streams[i]):
-                v = views[i]
-                engines[i].prefill(Bs, Bs, v["enc"], v["am"], v["pids"], v["pm"], v["pat"], v["raw"], start_len)
-        remaining, L_out = L - start_len, L
-        while remaining > 0:
-            n = min(64, remaining)
-            for i in range(nmb):
-                with torch.cuda.stream(self._streams[i]):
-                    engines[i].decode_steps(n, sp, self.profile_every if i == 0 else 0)
-            remaining -= n
-            if gen.eos_token_id is not None and self._may_finish_early():
-                dl = []
-                for i in range(nmb):
-                    with torch.cuda.stream(self._streams[i]):
-                        dl.append(engines[i].state().done_len)
-                if all(dl):
-                    L_out = max(dl)
-                    break
-        for i in range(nmb):
-            self._streams[i].synchronize()
-            raw_ids[i * Bs * K:(i + 1) * Bs * K] = views[i]["raw"]
-        return L_out
 
     def _may_finish_early(self) -> bool:
         # with the synthetic never-EOS heads no row can finish; real checkpoints poll every chunk
