@@ -39,6 +39,8 @@ template <typename P> struct Tile;
 template <> struct Tile<PBF16> {
     typedef bf16x8 wfrag;  // 8 bf16 per lane
     static __device__ inline wfrag load_global(const uint16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+    // weights are read exactly once per step: non-temporal loads keep them from displacing reusable lines
+    static __device__ inline wfrag load_weights(const uint16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
     static __device__ inline void mma(const wfrag& a, const wfrag& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
@@ -50,6 +52,7 @@ template <> struct Tile<PBF16> {
 template <> struct Tile<PF32> {
     typedef f32x4 wfrag;
     static __device__ inline wfrag load_global(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ inline wfrag load_weights(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
     static __device__ inline void mma(const wfrag& a, const wfrag& b, f32x4& c) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[m], c, 0, 0, 0);
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             if (ks < cend) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i)
-                    wt[u][i] = T::load_global(Wp + ((size_t)(nb0 + i) * ksteps + ks) * TILE + lane * EPL);
+                    wt[u][i] = T::load_weights(Wp + ((size_t)(nb0 + i) * ksteps + ks) * TILE + lane * EPL);
             }
         }
     };
@@ -352,7 +355,7 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
         return launch_one<P, 4, 1, true, 4>(a, stream);
     }
     // fragment input: enough K-split that a wave streams <= ~8 tiles in one burst
-    const int nw = ksteps > 64 ? 16 : (ksteps > 32 ? 8 : 4);
+    const int nw = ksteps > 64 ? 16 : (ksteps > 16 ? 8 : 4);   // <= 8 (K<=2048 bf16) / 4 tiles in flight per wave
     if (nw == 16) return launch_one<P, 16, 1, false, 1>(a, stream);
     if (nw == 8) return launch_one<P, 8, 1, false, 1>(a, stream);
     return launch_one<P, 4, 1, false, 1>(a, stream);

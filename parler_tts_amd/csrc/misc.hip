@@ -7,6 +7,21 @@ namespace {
 
 // ---- embedding: x[b] = ((((0 + E0[t0]) + E1[t1]) + ...) + E_{K-1}[t_{K-1}]) + pos_table[pos]
 // strictly left-to-right like Python's sum() at M:836, then the position row (M:884-886).
+template <typename P> struct Vec4;
+template <> struct Vec4<PBF16> {
+    static __device__ inline void load(const uint16_t* p, float* f) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        f[0] = __builtin_bit_cast(float, v.x << 16); f[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+        f[2] = __builtin_bit_cast(float, v.y << 16); f[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+    }
+};
+template <> struct Vec4<PF32> {
+    static __device__ inline void load(const float* p, float* f) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
+};
+
 template <typename P>
 __global__ __launch_bounds__(256) void embed_codebooks_kernel(EmbedArgs a) {
     typedef typename P::elem_t elem_t;
@@ -17,20 +32,25 @@ __global__ __launch_bounds__(256) void embed_codebooks_kernel(EmbedArgs a) {
     __syncthreads();
     const elem_t* tab = reinterpret_cast<const elem_t*>(a.tables);
     const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)pos * a.D;
-    // the K row gathers of one output element are independent loads (issued together); the sum order
-    // stays strictly left to right
-    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-        float e[16];
+    // 4 features per thread (D % 4 == 0); the K row gathers are independent vector loads issued together,
+    // the sum order stays strictly left to right per feature
+    for (int d = 4 * threadIdx.x; d < a.D; d += 4 * blockDim.x) {
+        float e[16][4];
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            if (k < a.K) e[k] = from_elem<P>(tab[((size_t)k * a.rows + toks[k]) * a.D + d]);
-        const float pe = from_elem<P>(ptab[d]);
-        float s = 0.f;
+            if (k < a.K) Vec4<P>::load(tab + ((size_t)k * a.rows + toks[k]) * a.D + d, e[k]);
+        float pe[4];
+        Vec4<P>::load(ptab + d, pe);
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            if (k < a.K) s = s + e[k];
-        for (int k = 16; k < a.K; ++k) s = s + from_elem<P>(tab[((size_t)k * a.rows + toks[k]) * a.D + d]);
-        a.x[(size_t)b * a.D + d] = s + pe;
+            if (k < a.K) { s[0] = s[0] + e[k][0]; s[1] = s[1] + e[k][1]; s[2] = s[2] + e[k][2]; s[3] = s[3] + e[k][3]; }
+        for (int k = 16; k < a.K; ++k) {
+            float t[4];
+            Vec4<P>::load(tab + ((size_t)k * a.rows + toks[k]) * a.D + d, t);
+            s[0] = s[0] + t[0]; s[1] = s[1] + t[1]; s[2] = s[2] + t[2]; s[3] = s[3] + t[3];
+        }
+        *reinterpret_cast<float4*>(a.x + (size_t)b * a.D + d) = make_float4(s[0] + pe[0], s[1] + pe[1], s[2] + pe[2], s[3] + pe[3]);
     }
 }
 
