@@ -19,6 +19,12 @@
 // wave 32 rows x TN; per 16-channel chunk the input window (TM + halo rows, Snake applied) and the
 // weights of all taps are staged in LDS; fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain:
 // the waveform must match the CPU reference to 1e-4 rms, which rules out plain bf16 operands).
+//
+// conv_kernel_h3 is the fast path for Cin % 32 == 0: every fp32 operand is split x = hi + lo with hi, lo
+// in fp16 (11-bit mantissas: hi + lo carries 22 bits) and a product is hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation: fp32-class accuracy (dropped term ~2^-22 relative)
+// at 3/16 of the matrix-pipe time of the fp32 MFMA.  Weights are split once at load, activations
+// while they are staged (after Snake).  256 time rows x TN outputs per 8-wave workgroup, 32-channel chunks.
 #include "ptts_common.h"
 #include "conv.h"
 
@@ -143,6 +149,145 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
 }
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr int TM3 = 256;      // time rows per workgroup (8 waves x 32)
+constexpr int KC3 = 32;       // channels per chunk = one fp16 MFMA k-step
+constexpr int LDH = KC3 + 8;  // padded row stride in halves (80 B: conflict-light 16-byte reads)
+
+__device__ inline void split_h(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int TN>
+__global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = TN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n0 = blockIdx.x * TN;
+    const int u0 = blockIdx.y * TM3;
+    const int b = blockIdx.z;
+    const int lo_r = a.tstep >= 0 ? a.toff : a.toff + (a.taps - 1) * a.tstep;
+    const int hi_r = a.tstep >= 0 ? a.toff + (a.taps - 1) * a.tstep : a.toff;
+    const int win = TM3 + (hi_r - lo_r);
+    _Float16* xh = reinterpret_cast<_Float16*>(smem);            // [win][LDH] hi
+    _Float16* xl = xh + (size_t)win * LDH;                       // [win][LDH] lo
+    _Float16* wh = xl + (size_t)win * LDH;                       // [taps][TN][LDH] hi
+    _Float16* wl = wh + (size_t)a.taps * TN * LDH;               // [taps][TN][LDH] lo
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = {0, 0, 0, 0};
+
+    const float* inb = a.in + (size_t)b * a.Tin * a.Cin;
+    const _Float16* gwh = reinterpret_cast<const _Float16*>(a.w_hi);
+    const _Float16* gwl = reinterpret_cast<const _Float16*>(a.w_lo);
+    for (int c0 = 0; c0 < a.Cin; c0 += KC3) {
+        // ---- stage the input window: Snake once per element, then the fp16 hi/lo split ----
+        for (int i = tid; i < win * (KC3 / 4); i += 512) {
+            const int r = i / (KC3 / 4), q = i % (KC3 / 4);
+            const int t = u0 + lo_r + r;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (t >= 0 && t < a.Tin) {
+                v = *reinterpret_cast<const float4*>(inb + (size_t)t * a.Cin + c0 + 4 * q);
+                if (a.alpha) {
+                    const float4 al = *reinterpret_cast<const float4*>(a.alpha + c0 + 4 * q);
+                    v.x = snake_f(v.x, al.x, 1.0f / (al.x + 1e-9f));
+                    v.y = snake_f(v.y, al.y, 1.0f / (al.y + 1e-9f));
+                    v.z = snake_f(v.z, al.z, 1.0f / (al.z + 1e-9f));
+                    v.w = snake_f(v.w, al.w, 1.0f / (al.w + 1e-9f));
+                }
+            }
+            _Float16 h[4], l[4];
+            split_h(v.x, h[0], l[0]); split_h(v.y, h[1], l[1]); split_h(v.z, h[2], l[2]); split_h(v.w, h[3], l[3]);
+            *reinterpret_cast<uint2*>(xh + (size_t)r * LDH + 4 * q) = *reinterpret_cast<uint2*>(h);
+            *reinterpret_cast<uint2*>(xl + (size_t)r * LDH + 4 * q) = *reinterpret_cast<uint2*>(l);
+        }
+        // ---- stage the pre-split weights of every tap for this chunk (16-byte copies) ----
+        for (int i = tid; i < a.taps * TN * (KC3 / 8); i += 512) {
+            const int q = i % (KC3 / 8), n = (i / (KC3 / 8)) % TN, tap = i / ((KC3 / 8) * TN);
+            uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+            if (n0 + n < a.N) {
+                const size_t g = ((size_t)tap * a.N + n0 + n) * a.Cin + c0 + 8 * q;
+                vh = *reinterpret_cast<const uint4*>(gwh + g);
+                vl = *reinterpret_cast<const uint4*>(gwl + g);
+            }
+            *reinterpret_cast<uint4*>(wh + ((size_t)tap * TN + n) * LDH + 8 * q) = vh;
+            *reinterpret_cast<uint4*>(wl + ((size_t)tap * TN + n) * LDH + 8 * q) = vl;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < a.taps; ++tap) {
+            const int roff = tap * a.tstep + a.toff - lo_r;
+            const size_t xo = (size_t)(w * 32 + roff + (lane & 15)) * LDH + 8 * (lane >> 4);
+            const half8 x0h = *reinterpret_cast<const half8*>(xh + xo);
+            const half8 x0l = *reinterpret_cast<const half8*>(xl + xo);
+            const half8 x1h = *reinterpret_cast<const half8*>(xh + xo + 16 * LDH);
+            const half8 x1l = *reinterpret_cast<const half8*>(xl + xo + 16 * LDH);
+            const size_t wo = ((size_t)tap * TN + (lane & 15)) * LDH + 8 * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const half8 bh = *reinterpret_cast<const half8*>(wh + wo + (size_t)j * 16 * LDH);
+                const half8 bl = *reinterpret_cast<const half8*>(wl + wo + (size_t)j * 16 * LDH);
+                // small terms first, then the leading term
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, x0h, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x0l, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x0h, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, x1h, acc[1][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x1l, acc[1][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x1h, acc[1][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (same as the fp32 kernel) ----
+    float* outb = a.out + (size_t)b * a.Tout * a.Cout;
+    const float* resb = a.res ? a.res + (size_t)b * a.Tout * a.Cout : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = u0 + w * 32 + i * 16 + (lane & 15);
+        if (u >= a.U) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + 4 * (lane >> 4);
+            if (n >= a.N) continue;
+            int t, co;
+            if (a.stride == 1) { t = u; co = n; }
+            else { const int r = n / a.Cout; co = n - r * a.Cout; t = a.stride * u - a.pad_t + r; }
+            if (t < 0 || t >= a.Tout) continue;
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + (co + e < a.Cout ? a.bias[co + e] : 0.f);
+            float* o = outb + (size_t)t * a.Cout + co;
+            if (co + 3 < a.Cout) {
+                if (resb) {
+                    const float4 rv = *reinterpret_cast<const float4*>(resb + (size_t)t * a.Cout + co);
+                    y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w;
+                }
+                if (a.act_out == 1) { y[0] = tanhf(y[0]); y[1] = tanhf(y[1]); y[2] = tanhf(y[2]); y[3] = tanhf(y[3]); }
+                *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+                for (int e = 0; e < 4 && co + e < a.Cout; ++e) {
+                    float v = y[e];
+                    if (resb) v += resb[(size_t)t * a.Cout + co + e];
+                    if (a.act_out == 1) v = tanhf(v);
+                    o[e] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void split_halves_kernel(const float* src, _Float16* hi, _Float16* lo, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    _Float16 h, l;
+    split_h(src[i], h, l);
+    hi[i] = h; lo[i] = l;
+}
+
 // z[b][f][c] = sum_k table[k][codes[b][k][f]][c]   (left to right over codebooks, as from_codes adds them)
 __global__ void dac_latent_kernel(const long long* codes, const float* table, float* z, int K, int F, int C, int ncodes) {
     const int f = blockIdx.x, b = blockIdx.y;
@@ -190,11 +335,34 @@ __global__ void conv_pack_kernel(const float* w, float* out, int Cout, int Cin, 
 hipError_t conv_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+size_t conv_h3_lds(const ConvArgs& a, int TN) {
+    const int lo = a.tstep >= 0 ? a.toff : a.toff + (a.taps - 1) * a.tstep;
+    const int hi = a.tstep >= 0 ? a.toff + (a.taps - 1) * a.tstep : a.toff;
+    const int win = TM3 + (hi - lo);
+    return ((size_t)2 * win * LDH + (size_t)2 * a.taps * TN * LDH) * sizeof(_Float16);
 }
 
 hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     if (a.taps > MAX_TAPS || a.Cin % KC != 0) return hipErrorInvalidValue;
+    if (a.w_hi && a.w_lo && a.Cin % KC3 == 0) {
+        // TN = 96 when it divides N and fits LDS, else 64
+        int TN = (a.N % 96 == 0 && conv_h3_lds(a, 96) <= 160 * 1024) ? 96 : 64;
+        if (a.N % 64 != 0 && a.N % 96 != 0) TN = a.N <= 64 ? 64 : 96;
+        const size_t lds3 = conv_h3_lds(a, TN);
+        if (lds3 <= 160 * 1024) {
+            dim3 grid((a.N + TN - 1) / TN, (a.U + TM3 - 1) / TM3, a.B);
+            if (TN == 64) hipLaunchKernelGGL(conv_kernel_h3<64>, grid, dim3(512), lds3, s, a);
+            else hipLaunchKernelGGL(conv_kernel_h3<96>, grid, dim3(512), lds3, s, a);
+            return hipGetLastError();
+        }
+    }
     const int lo = a.tstep >= 0 ? a.toff : a.toff + (a.taps - 1) * a.tstep;
     const int hi = a.tstep >= 0 ? a.toff + (a.taps - 1) * a.tstep : a.toff;
     const int win = TM + (hi - lo);
@@ -224,5 +392,10 @@ hipError_t conv_pack_launch(const float* w, float* out, int Cout, int Cin, int k
     size_t total = (size_t)(transposed ? 2 : k) * N * Cin;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, Cout, Cin, k,
                        transposed, stride, N);
+    return hipGetLastError();
+}
+
+hipError_t split_halves_launch(const float* src, void* hi, void* lo, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(split_halves_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (_Float16*)hi, (_Float16*)lo, n);
     return hipGetLastError();
 }

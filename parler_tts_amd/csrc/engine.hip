@@ -63,6 +63,7 @@ struct T5Layer {
 
 struct ConvLayer {
     float *w = nullptr, *bias = nullptr, *alpha = nullptr;   // packed weight, bias, Snake alpha of the INPUT
+    void *w_hi = nullptr, *w_lo = nullptr;                    // fp16 hi/lo split of `w` (fast conv path)
     int Cin = 0, Cout = 0, k = 1, dil = 1, stride = 1;
     bool transposed = false, have_w = false, have_b = false, have_a = false, needs_alpha = false;
 };
@@ -112,6 +113,7 @@ struct ptts_engine {
     float* dac_table = nullptr;
     bool dac_table_ready = false;
     float *dac_buf0 = nullptr, *dac_buf1 = nullptr;
+    bool dac_f32_only = false;   // PTTS_DAC_F32=1: keep every conv on the fp32 MFMA kernel (cross-check)
     size_t dac_buf_floats = 0;
     // T5 workspaces
     float *t5_x = nullptr, *t5_qkv = nullptr;
@@ -455,6 +457,11 @@ int load_dac_tensor(ptts_engine* e, const std::string& n, const float* data, con
         const int taps = L.transposed ? 2 : L.k;
         if (!L.w) PTTS_TRY(dev_alloc(e, (void**)&L.w, (size_t)taps * N * L.Cin * sizeof(float)));
         HIP_TRY(conv_pack_launch(data, L.w, L.Cout, L.Cin, L.k, L.transposed ? 1 : 0, L.stride, N, s));
+        if (L.Cin % 32 == 0 && !e->dac_f32_only) {
+            const size_t n = (size_t)taps * N * L.Cin;
+            if (!L.w_hi) { PTTS_TRY(dev_alloc(e, &L.w_hi, n * 2)); PTTS_TRY(dev_alloc(e, &L.w_lo, n * 2)); }
+            HIP_TRY(split_halves_launch(L.w, L.w_hi, L.w_lo, n, s));
+        }
         L.have_w = true;
         return PTTS_OK;
     }
@@ -495,6 +502,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->layers.resize(cfg->layers);
     e->t5.resize(cfg->t5_layers > 0 ? cfg->t5_layers : 0);
     e->no_graph = getenv("PTTS_NO_GRAPH") != nullptr;
+    e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     if (cfg->dac_hidden > 0) {
         if (cfg->dac_n_up <= 0 || cfg->dac_n_up > 8 || cfg->dac_hidden % (16 << cfg->dac_n_up) != 0 || cfg->dac_latent % 16 != 0) {
             delete e;
@@ -976,7 +984,7 @@ int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, 
             const ConvLayer& L = e->dac[i];
             const bool last = i + 1 == e->dac.size();
             ConvArgs a;
-            a.in = cur; a.w = L.w; a.bias = L.bias; a.alpha = L.needs_alpha ? L.alpha : nullptr;
+            a.in = cur; a.w = L.w; a.w_hi = L.w_hi; a.w_lo = L.w_lo; a.bias = L.bias; a.alpha = L.needs_alpha ? L.alpha : nullptr;
             a.B = nb; a.Tin = T; a.Cin = L.Cin; a.Cout = L.Cout;
             if (L.transposed) {
                 a.Tout = T * L.stride; a.N = L.stride * L.Cout; a.U = T + 1; a.taps = 2; a.tstep = -1; a.toff = 0;
