@@ -119,8 +119,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # "nccl" is RCCL over xGMI on ROCm.  PTTS_DIST_BACKEND=gloo + PTTS_SHARE_GPU=1 rehearse the N>1 path on
+        # a single-GPU box (all ranks on cuda:0, collectives through host memory).
+        backend = os.environ.get("PTTS_DIST_BACKEND", "nccl")
+        if os.environ.get("PTTS_SHARE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -160,12 +168,14 @@ def main():
         out = model.generate(**kw)
         if dist is not None:   # data-parallel plumbing: gather the codec ids of every rank (RCCL over xGMI)
             codes = model.last_codes[0].to(torch.int32)
+            if dist.get_backend() != "nccl":
+                codes = codes.cpu()
             gathered = [torch.empty_like(codes) for _ in range(world)]
             dist.all_gather(gathered, codes)
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -179,8 +189,10 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_attn_traffic.json")
         if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.dtype)
+            try:   # PMC ratio (HBM fetch / algorithmic bytes) of the same kernel, collected in separate --pmc passes
+                ratio = json.load(open(pmc)).get(args.dtype, {}).get("fetchx2_over_algo")
+                if ratio and prof.launches:
+                    traffic = round(ratio * prof.algo_bytes / prof.launches)
             except Exception:
                 traffic = None
         line = {

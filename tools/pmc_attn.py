@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Torch-free driver for PMC runs (rocprofv3 --pmc crashes inside the profiler when PyTorch is loaded on
+this image).  Builds a 2-layer engine at mini_v0.1 widths through the C ABI with numpy + libamdhip64 only,
+runs a bf16 batch-32 greedy decode to S = max_length, so that the self-attention kernel's HBM traffic
+(FETCH_SIZE) can be compared with its algorithmic bytes 2*B*S*D*2 per launch.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python3 tools/pmc_attn.py [L]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from parler_tts_amd import _hip  # noqa: E402  (ctypes structs only; no torch import)
+
+hip = C.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+hip.hipDeviceSynchronize.argtypes = []
+
+
+def dev(arr):
+    arr = np.ascontiguousarray(arr)
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), max(arr.nbytes, 16)) == 0
+    assert hip.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1) == 0
+    return p
+
+
+def main():
+    L = int(sys.argv[1]) if len(sys.argv) > 1 else 1400
+    lib = _hip.load_library()
+    NL = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    B, T, D, H, F, V, K, ENC = 32, 40, 1024, 16, 4096, 1088, 9, 768
+    c = _hip.PttsConfig()
+    c.abi_version, c.dtype = _hip.ABI_VERSION, _hip.DTYPE_BF16
+    c.hidden, c.layers, c.heads, c.ffn, c.vocab, c.codebooks, c.max_positions = D, NL, H, F, V, K, 4096
+    c.pad_token_id, c.eos_token_id, c.bos_token_id = 1024, 1024, 1025
+    c.prompt_vocab, c.enc_hidden, c.t5_layers = 64, ENC, 0
+    c.max_batch, c.max_desc_len, c.max_prompt_len, c.max_length = B, T, 0, L
+    h = C.c_void_p()
+    _hip.check(lib.ptts_create(C.byref(c), C.byref(h)))
+    rng = np.random.default_rng(0)
+
+    def load(name, shape, std=0.02, ones=False, zero_from=None):
+        a = np.ones(shape, np.float32) if ones else (rng.standard_normal(shape, dtype=np.float32) * std)
+        if zero_from is not None:
+            a[zero_from:] = 0
+        sh = (C.c_int64 * len(shape))(*shape)
+        _hip.check(lib.ptts_load_tensor(h, name.encode(), dev(a), sh, len(shape), None))
+
+    p = "decoder.model.decoder."
+    for k in range(K):
+        load(f"{p}embed_tokens.{k}.weight", (V + 1, D))
+        load(f"decoder.lm_heads.{k}.weight", (V, D), zero_from=1024)
+    load(f"{p}embed_positions.weights", (4096, D), std=0.5)
+    load(f"{p}layer_norm.weight", (D,), ones=True)
+    load(f"{p}layer_norm.bias", (D,), std=0.0)
+    load("embed_prompts.weight", (64, D))
+    load("enc_to_dec_proj.weight", (D, ENC))
+    load("enc_to_dec_proj.bias", (D,))
+    for l in range(NL):
+        q = f"{p}layers.{l}."
+        for a in ("self_attn", "encoder_attn"):
+            for pr in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                load(f"{q}{a}.{pr}.weight", (D, D))
+        for ln in ("self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm"):
+            load(f"{q}{ln}.weight", (D,), ones=True)
+            load(f"{q}{ln}.bias", (D,), std=0.0)
+        load(f"{q}fc1.weight", (F, D))
+        load(f"{q}fc2.weight", (D, F))
+    hip.hipDeviceSynchronize()
+    _hip.check(lib.ptts_weights_ready(h))
+    enc = dev(rng.standard_normal((B, T, ENC), dtype=np.float32))
+    amask = dev(np.ones((B, T), np.int32))
+    pattern = np.full((B * K, L), -1, np.int64)
+    pattern[:, 0] = 1025
+    raw = np.full((B * K, L), 1024, np.int64)
+    raw[:, 0] = 1025
+    d_pat, d_raw = dev(pattern), dev(raw)
+    _hip.check(lib.ptts_prefill(h, B, B, T, 0, L, enc, amask, None, None, d_pat, d_raw, 1, None))
+    sp = _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
+    _hip.check(lib.ptts_decode_steps(h, L - 1, C.byref(sp), 0, None))
+    hip.hipDeviceSynchronize()
+    st = _hip.PttsState()
+    _hip.check(lib.ptts_get_state(h, C.byref(st), None))
+    print(f"done: cur_len={st.cur_len} pos={st.pos} layers={NL} B={B} D={D}", flush=True)
+    lib.ptts_destroy(h)
+
+
+if __name__ == "__main__":
+    main()
