@@ -438,3 +438,80 @@ def test_baseline_size_invariants_bf16_batch32(hip):
     assert bool((raw.cpu()[free] < 1024).all())
     del model
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------
+# API surface of generate(): streamer, guidance, ragged masks end to end, checkpoint round trip
+# ------------------------------------------------------------------------------------------------
+def test_generate_ragged_masks_end_to_end(hip):
+    """description mask (right padded) + left-padded prompt mask, T5 on device, vs the reference fixture"""
+    f, meta = load_case("tiny_greedy_ragged")
+    cfg, model = model_for("tiny_greedy_ragged", meta, "fp32")
+    desc, amask, prompt, pmask = case_inputs(f)
+    codes = model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, prompt_attention_mask=pmask,
+                           do_sample=False, max_length=int(f["max_length"]), return_raw_ids=True)
+    assert np.array_equal(codes[0].cpu().numpy(), f["codes"])
+
+
+def test_generate_with_guidance_scale(hip):
+    f, meta = load_case("tiny_cfg")
+    cfg, model = model_for("tiny_cfg", meta, "fp32")
+    desc, amask, prompt, _ = case_inputs(f)
+    codes = model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False,
+                           guidance_scale=3.0, max_length=int(f["max_length"]), return_raw_ids=True)
+    assert np.array_equal(codes[0].cpu().numpy(), f["codes"])
+
+
+def test_streamer_protocol(hip):
+    """put(start ids) once, then one put per generated column, then end() (M:2540-2541 + the HF loop)"""
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, "fp32")
+    desc, amask, prompt, _ = case_inputs(f)
+
+    class Rec:
+        def __init__(self):
+            self.items, self.ended = [], False
+
+        def put(self, t):
+            assert t.device.type == "cpu"
+            self.items.append(t.clone())
+
+        def end(self):
+            self.ended = True
+
+    r = Rec()
+    L = int(f["max_length"])
+    model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L,
+                   streamer=r, return_raw_ids=True)
+    assert r.ended and len(r.items) == L          # 1 (start ids) + L-1 steps
+    assert r.items[0].shape == (12, 1) and bool((r.items[0] == cfg.decoder.bos_token_id).all())
+    streamed = torch.stack(r.items[1:], dim=1)
+    assert torch.equal(streamed, model.last_raw_ids.cpu()[:, 1:])
+
+
+def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
+    from parler_tts_amd.configuration import GenerationConfig
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import save_pretrained
+
+    f, meta = load_case("tiny_greedy")
+    cfg, sd = state_dict_for("tiny_greedy", meta, parts=("text_encoder", "decoder", "audio_encoder"))
+    # write the codec convs the way a descript checkpoint stores them: weight_g / weight_v pairs
+    disk = {}
+    for k, v in sd.items():
+        if k.startswith("audio_encoder.") and k.endswith(".weight") and v.dim() == 3:
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+            disk[k[:-len("weight")] + "weight_g"] = norm.clone()
+            disk[k[:-len("weight")] + "weight_v"] = (v * 1.7).clone()      # any positive rescale of v folds back
+        else:
+            disk[k] = v
+    save_pretrained(str(tmp_path), cfg, disk, GenerationConfig(max_length=24, do_sample=False,
+                    pad_token_id=cfg.decoder.pad_token_id, eos_token_id=cfg.decoder.eos_token_id,
+                    bos_token_id=cfg.decoder.bos_token_id, decoder_start_token_id=cfg.decoder.bos_token_id))
+    model = ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path), dtype="fp32")
+    assert model.config.sampling_rate == 44100 and model.generation_config.max_length == 24
+    desc, amask, prompt, _ = case_inputs(f)
+    wav = model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt)   # config defaults: greedy, L=24
+    assert np.array_equal(model.last_codes[0].cpu().numpy(), f["codes"])
+    assert wav.shape == (3, f["codes"].shape[-1] * cfg.audio_encoder.hop_length)
+    _models.clear()
