@@ -25,6 +25,8 @@
 namespace {
 
 constexpr int U = 8;  // weight tiles in flight per wave
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ inline float act_apply(int act, float x) {
     if (act == ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -178,10 +180,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             }
         }
     };
-    {
-        const int cend0 = cstep < ksteps ? cstep : ksteps;
-        load_burst(w, cend0);
-    }
+    // Loads return in issue order (vmcnt), so the L2-resident activation rows and the LayerNorm
+    // affine go out FIRST and the HBM weight tiles right behind them: the normalisation then waits
+    // only for what it needs while the weights are still in flight.
+    const int cend0 = cstep < ksteps ? cstep : ksteps;
+    if (!STAGE) load_burst(w, cend0);
 
     for (int c0 = 0; c0 < ksteps; c0 += cstep) {
         const int cend = (c0 + cstep < ksteps) ? c0 + cstep : ksteps;
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             // ---- wave per row, RB rows at a time: fp32 rows -> registers, (LN | RMS), convert, park in LDS ----
             if (c0 > 0) __syncthreads();
             const int kbase = c0 * KSTEP, klen = (cend - c0) * KSTEP;
+            float4 gam[KI], bet[KI];
             for (int rb = 0; rb < RPW; rb += RB) {
                 float4 v[RB][KI];
 #pragma unroll
@@ -201,67 +205,82 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                         v[j][i] = (k < klen) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0, 0, 0, 0);
                     }
                 }
-                float mean[RB], rstd[RB];
+                if (rb == 0) {
 #pragma unroll
-                for (int j = 0; j < RB; ++j) { mean[j] = 0.f; rstd[j] = 1.f; }
+                    for (int i = 0; i < KI; ++i) {
+                        const int k = 4 * lane + 256 * i;
+                        gam[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                        bet[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (norm && k < klen) {
+                            gam[i] = *reinterpret_cast<const float4*>(a.gamma + kbase + k);
+                            if (a.pro == PRO_LAYERNORM) bet[i] = *reinterpret_cast<const float4*>(a.beta + kbase + k);
+                        }
+                    }
+                    if (c0 == 0) load_burst(w, cend0);      // weight tiles queue up behind the rows
+                }
+                // packed fp32 math (v_pk_add/mul/fma_f32 on float2): the prologue is VALU-issue bound because
+                // every workgroup normalises all 32 rows; ~3 wave-instructions per element pair
+                float scale[RB], shift[RB];     // y = (x * scale + shift) * gamma + beta   (ATen's LayerNorm form)
+#pragma unroll
+                for (int j = 0; j < RB; ++j) { scale[j] = 1.f; shift[j] = 0.f; }
                 if (norm) {   // whole row is in this chunk (host guarantees K <= KC for LN/RMS)
                     const float invK = 1.0f / (float)K;
+                    float mean[RB];
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) mean[j] = 0.f;
                     if (a.pro == PRO_LAYERNORM) {
 #pragma unroll
                         for (int j = 0; j < RB; ++j) {
-                            float sm = 0.f;
+                            v2f sm = {0.f, 0.f};
 #pragma unroll
-                            for (int i = 0; i < KI; ++i) sm += (v[j][i].x + v[j][i].y) + (v[j][i].z + v[j][i].w);
-                            mean[j] = wave_sum(sm) * invK;
+                            for (int i = 0; i < KI; ++i) sm += v2f{v[j][i].x, v[j][i].y} + v2f{v[j][i].z, v[j][i].w};
+                            mean[j] = wave_sum(sm[0] + sm[1]) * invK;
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < RB; ++j) {
-                        float q = 0.f;
+                        v2f q = {0.f, 0.f};
+                        const v2f mm = {mean[j], mean[j]};
 #pragma unroll
                         for (int i = 0; i < KI; ++i) {
                             if (4 * lane + 256 * i < klen) {
-                                const float d0 = v[j][i].x - mean[j], d1 = v[j][i].y - mean[j];
-                                const float d2 = v[j][i].z - mean[j], d3 = v[j][i].w - mean[j];
-                                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                                const v2f d0 = v2f{v[j][i].x, v[j][i].y} - mm, d1 = v2f{v[j][i].z, v[j][i].w} - mm;
+                                q = d0 * d0 + q;
+                                q = d1 * d1 + q;
                             }
                         }
-                        rstd[j] = 1.0f / sqrtf(wave_sum(q) * invK + a.eps);
+                        const float rstd = 1.0f / sqrtf(wave_sum(q[0] + q[1]) * invK + a.eps);
+                        scale[j] = rstd;
+                        shift[j] = -rstd * mean[j];
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < KI; ++i) {
                     const int k = 4 * lane + 256 * i;
                     if (k < klen) {
-                        float gg[4] = {1.f, 1.f, 1.f, 1.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (norm) {
-                            const float4 g = *reinterpret_cast<const float4*>(a.gamma + kbase + k);
-                            gg[0] = g.x; gg[1] = g.y; gg[2] = g.z; gg[3] = g.w;
-                            if (a.pro == PRO_LAYERNORM) {
-                                const float4 bt = *reinterpret_cast<const float4*>(a.beta + kbase + k);
-                                bb[0] = bt.x; bb[1] = bt.y; bb[2] = bt.z; bb[3] = bt.w;
-                            }
-                        }
+                        const v2f g0 = {gam[i].x, gam[i].y}, g1 = {gam[i].z, gam[i].w};
+                        const v2f b0 = {bet[i].x, bet[i].y}, b1 = {bet[i].z, bet[i].w};
 #pragma unroll
                         for (int j = 0; j < RB; ++j) {
-                            float y[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
+                            v2f y0 = {v[j][i].x, v[j][i].y}, y1 = {v[j][i].z, v[j][i].w};
                             if (norm) {
+                                const v2f sc = {scale[j], scale[j]}, sh = {shift[j], shift[j]};
                                 if (a.pro == PRO_LAYERNORM) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean[j]) * rstd[j] * gg[e] + bb[e];
-                                } else {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) y[e] = gg[e] * (y[e] * rstd[j]);
+                                    y0 = (y0 * sc + sh) * g0 + b0;
+                                    y1 = (y1 * sc + sh) * g1 + b1;
+                                } else {   // T5 RMSNorm: w * (x * rsqrt(mean(x^2) + eps))
+                                    y0 = g0 * (y0 * sc);
+                                    y1 = g1 * (y1 * sc);
                                 }
                             }
                             elem_t* dst = xs + (size_t)(w * RPW + rb + j) * ld + k;
                             if (P::IS_BF16) {
-                                uint2 pk;
-                                pk.x = (uint32_t)float_to_bf16_bits(y[0]) | ((uint32_t)float_to_bf16_bits(y[1]) << 16);
-                                pk.y = (uint32_t)float_to_bf16_bits(y[2]) | ((uint32_t)float_to_bf16_bits(y[3]) << 16);
+                                uint2 pk;   // one v_cvt_pk_bf16_f32 per pair
+                                pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(y0, bf16x2));
+                                pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(y1, bf16x2));
                                 *reinterpret_cast<uint2*>(dst) = pk;
                             } else {
-                                *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+                                *reinterpret_cast<float4*>(dst) = make_float4(y0[0], y0[1], y1[0], y1[1]);
                             }
                         }
                     }
