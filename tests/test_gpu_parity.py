@@ -515,3 +515,76 @@ def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
     assert np.array_equal(model.last_codes[0].cpu().numpy(), f["codes"])
     assert wav.shape == (3, f["codes"].shape[-1] * cfg.audio_encoder.hop_length)
     _models.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# shapes beyond the fixtures: more than one 32-row m-tile, and BASELINE configs[4] (scaled decoder)
+# ------------------------------------------------------------------------------------------------
+def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps):
+    """teacher-forced along the ORACLE's greedy path; returns (engine logits, oracle logits, oracle ids)"""
+    from oracle import cpu_ref
+    from parler_tts_amd import _hip
+    from parler_tts_amd.delay_pattern import build_delay_pattern_mask
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+
+    g = torch.Generator().manual_seed(seed)
+    desc = torch.randint(2, cfg.text_encoder.vocab_size, (B, T), generator=g)
+    prompt = torch.randint(2, cfg.vocab_size, (B, P), generator=g)
+    amask = torch.ones(B, T, dtype=torch.long)
+    enc = cpu_ref.t5_encode(cfg, sd, desc, amask)
+    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, None, L, record_logits=steps)
+    _models.clear()
+    torch.cuda.empty_cache()
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=dtype, device="cuda:0")
+    eng = model.engine(B, T, P, L)
+    K = cfg.decoder.num_codebooks
+    dev = "cuda:0"
+    ids = torch.full((B * K, 1), cfg.decoder.bos_token_id, dtype=torch.long)
+    ids, pattern = build_delay_pattern_mask(ids, cfg.decoder.bos_token_id, cfg.decoder.pad_token_id, L, K)
+    pattern = pattern.to(dev).contiguous()
+    raw = torch.full((B * K, L), cfg.decoder.pad_token_id, dtype=torch.long, device=dev)
+    raw[:, :1] = ids.to(dev)
+    eng.prefill(B, B, enc.to(dev).contiguous(), amask.to(dev, torch.int32).contiguous(), prompt.to(dev).contiguous(), None,
+                pattern, raw, 1)
+    sp = _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
+    out = []
+    for s in range(steps):
+        eng.set_forced_tokens(ref["raw_ids"][:, s + 1])
+        eng.decode_steps(1, sp)
+        out.append(eng.last_logits(B * K).cpu())
+    eng.set_forced_tokens(None)
+    got_raw = raw[:, : steps + 1].cpu()
+    del model
+    _models.clear()
+    torch.cuda.empty_cache()
+    return torch.stack(out), ref["step_logits"], ref["raw_ids"], got_raw
+
+
+def test_two_m_tiles_batch_40_fp32(hip):
+    """B = 40 > 32: GEMMs run two 32-row m-tiles, attention / select grids grow with the batch"""
+    from parler_tts_amd.configuration import tiny_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=11, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+    got, want, ref_ids, got_raw = _oracle_vs_engine(cfg, sd, "fp32", B=40, T=7, P=4, L=16, seed=3, steps=15)
+    assert (got - want).abs().max() < 2e-4
+    top2 = torch.topk(want, 2, dim=-1)[0]
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3            # only argmaxes the reference itself decides clearly
+    assert torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe])
+
+
+def test_scaled_decoder_config_bf16(hip):
+    """BASELINE configs[4]: d_model 1536, 24 heads, ffn 6144, 24 layers (random init; bf16 engine only:
+    the fp32 parity mode keeps LayerNorm rows <= 1024 wide in LDS)"""
+    from parler_tts_amd.configuration import scaled_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = scaled_config()
+    cfg.decoder.num_hidden_layers = 6          # same widths, fewer layers: keeps the CPU oracle to seconds
+    sd = synthetic_state_dict(cfg, seed=5, never_eos=True, parts=("text_encoder", "decoder"))
+    got, want, _, _ = _oracle_vs_engine(cfg, sd, "bf16", B=3, T=8, P=4, L=12, seed=4, steps=8)
+    assert (got - want).abs().max() < 0.08
+    top2 = torch.topk(want, 2, dim=-1)[0]
+    safe = (top2[..., 0] - top2[..., 1]) > 0.05
+    assert (got.argmax(-1)[safe] == want.argmax(-1)[safe]).float().mean() > 0.97
