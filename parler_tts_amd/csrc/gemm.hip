@@ -68,7 +68,7 @@ template <> struct Tile<PF32> {
 };
 
 template <typename P>
-__device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x4 v1) {
+__device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x4 v1, const float4& xres, bool have_res) {
     // row: absolute output row; n: first of this lane's 4 consecutive output features
     typedef typename P::elem_t elem_t;
     switch (a.epi) {
@@ -88,7 +88,7 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
         }
         case EPI_RESIDUAL: {
             float4* o = reinterpret_cast<float4*>(a.out + (size_t)row * a.ldo + n);
-            float4 x = *o;
+            float4 x = have_res ? xres : *o;     // the residual slice was requested at kernel entry
             x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
             *o = x;
             break;
@@ -165,6 +165,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     for (int i = 0; i < NB; ++i) { acc[i][0] = {0, 0, 0, 0}; acc[i][1] = {0, 0, 0, 0}; }
 
     const bool norm = STAGE && (a.pro == PRO_LAYERNORM || a.pro == PRO_RMSNORM);
+    // residual epilogue: thread t < NB*128 finishes outputs (row, n..n+3); fetch that slice of x now so the
+    // read-modify-write at the end does not start with a cold load
+    float4 xres = make_float4(0, 0, 0, 0);
+    bool have_res = false;
+    if (a.epi == EPI_RESIDUAL && tid < NB * 128) {
+        const int ln = tid & 63, hh = (tid >> 6) & 1, ii = tid >> 7;
+        const int row = m0 + 16 * hh + (ln & 15), n = (nb0 + ii) * 16 + 4 * (ln >> 4);
+        if (row < a.M && n < a.N) { xres = *reinterpret_cast<const float4*>(a.out + (size_t)row * a.ldo + n); have_res = true; }
+    }
     const int cstep = STAGE ? KC / KSTEP : ksteps;   // only the LDS-staged path needs K chunks
 
     // first burst of this wave's weight tiles: issued before the prologue so HBM latency hides under it
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         const int row = m0 + 16 * h + (ln & 15);
         if (row >= a.M) continue;
         const int n = gated ? blockIdx.x * 16 + 4 * (ln >> 4) : (nb0 + i) * 16 + 4 * (ln >> 4);
-        epilogue<P>(a, row, n, s, s1);
+        epilogue<P>(a, row, n, s, s1, xres, have_res && t == tid);
     }
 }
 
