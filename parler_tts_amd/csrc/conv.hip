@@ -36,7 +36,10 @@ constexpr int LDA = KC + 4;  // padded row strides (floats)
 constexpr int MAX_TAPS = 7;
 
 __device__ inline float snake_f(float x, float alpha, float inv) {
-    const float s = sinf(alpha * x);
+    // hardware sine (v_sin_f32 after a 1/2pi scale): the staging pass is VALU-bound in the narrow late blocks,
+    // where the full-range software sinf costs more than the MFMAs it feeds.  |alpha*x| stays O(10) in the
+    // codec, where the hardware sine is accurate to ~1e-6 absolute (waveform parity test: rms < 1e-5).
+    const float s = __sinf(alpha * x);
     return x + inv * (s * s);
 }
 
