@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 2
+#define PTTS_ABI_VERSION 3
 
 enum { PTTS_DTYPE_F32 = 0, PTTS_DTYPE_BF16 = 1 };
 
@@ -118,6 +118,7 @@ typedef struct ptts_sampling {
     int32_t top_k;           /* 0 = off */
     float guidance_scale;    /* > 1: rows [0,B*K) conditional, [B*K,2B*K) unconditional (M:2556-2558) */
     uint64_t seed;           /* Philox key; draws are (seed, row, step) so runs are reproducible */
+    float top_p;             /* nucleus warper applied after top-k; <= 0 or >= 1 = off */
 } ptts_sampling;
 
 /* ---- decode: n_steps iterations of {prepare_inputs_for_generation (M:2081-2148), forward

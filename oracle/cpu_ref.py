@@ -263,9 +263,11 @@ def encoder_glue(cfg: ParlerTTSConfig, sd, enc_last_hidden: torch.Tensor,
 # token selection (third party: transformers 4.3x GenerationMixin.greedy_search / .sample)
 # ----------------------------------------------------------------------------------------------
 
-def warp_logits(logits: torch.Tensor, temperature: float, top_k: int) -> torch.Tensor:
-    """TemperatureLogitsWarper then TopKLogitsWarper: scores/tau; everything below the k-th largest
-    value becomes -inf (ties at the threshold are kept)."""
+def warp_logits(logits: torch.Tensor, temperature: float, top_k: int, top_p: float = 1.0) -> torch.Tensor:
+    """TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper in the order `_get_logits_warper` builds
+    them: scores/tau; everything below the k-th largest value becomes -inf (ties at the threshold are kept);
+    then, in ascending order of probability, tokens whose cumulative probability is <= 1 - top_p are removed
+    (the most probable token always stays)."""
     s = logits
     if temperature is not None and temperature != 1.0:
         s = s / temperature
@@ -273,6 +275,12 @@ def warp_logits(logits: torch.Tensor, temperature: float, top_k: int) -> torch.T
         kk = min(top_k, s.shape[-1])
         thr = torch.topk(s, kk)[0][..., -1, None]
         s = s.masked_fill(s < thr, -float("inf"))
+    if top_p is not None and 0.0 < top_p < 1.0:
+        sorted_logits, sorted_idx = torch.sort(s, descending=False)
+        cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1 - top_p)
+        remove[..., -1:] = False
+        s = s.masked_fill(remove.scatter(-1, sorted_idx, remove), -float("inf"))
     return s
 
 
@@ -296,6 +304,7 @@ def generate_ids(
     do_sample: bool = False,
     temperature: float = 1.0,
     top_k: int = 50,
+    top_p: float = 1.0,
     guidance_scale: Optional[float] = None,
     generator: Optional[torch.Generator] = None,
     kv_mode: str = "cat",
@@ -353,7 +362,7 @@ def generate_ids(
         if step < record_logits:
             step_logits.append(logits.clone())
         if do_sample:
-            probs = F.softmax(warp_logits(logits, temperature, top_k), dim=-1)
+            probs = F.softmax(warp_logits(logits, temperature, top_k, top_p), dim=-1)
             nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
         else:
             top2 = torch.topk(logits, 2, dim=-1)[0]

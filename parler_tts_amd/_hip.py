@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libparler_tts_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 # every symbol include/parler_tts_hip.h declares (tests check the export table against this list)
@@ -40,7 +40,7 @@ class PttsConfig(C.Structure):
 
 class PttsSampling(C.Structure):
     _fields_ = [("do_sample", C.c_int32), ("temperature", C.c_float), ("top_k", C.c_int32),
-                ("guidance_scale", C.c_float), ("seed", C.c_uint64)]
+                ("guidance_scale", C.c_float), ("seed", C.c_uint64), ("top_p", C.c_float)]
 
 
 class PttsState(C.Structure):

@@ -334,6 +334,7 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
     sa.tok_in = e->tok_in; sa.force = e->use_force ? e->force : nullptr; sa.probs = e->probs;
     sa.pad = c.pad_token_id; sa.eos = c.eos_token_id; sa.do_sample = sp.do_sample; sa.top_k = sp.top_k;
     sa.temperature = sp.temperature; sa.guidance = sp.guidance_scale; sa.seed = sp.seed;
+    sa.top_p = (sp.top_p > 0.f && sp.top_p < 1.f) ? sp.top_p : 1.0f;
     HIP_TRY(select_launch(sa, s));   // the last row to finish also advances pos / cur_len / step_count
     if (step_ev) HIP_TRY(hipEventRecord(step_ev->b, s));
     return PTTS_OK;
@@ -341,7 +342,7 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
 
 bool same_sampling(const ptts_sampling& a, const ptts_sampling& b) {
     return a.do_sample == b.do_sample && a.temperature == b.temperature && a.top_k == b.top_k &&
-           a.guidance_scale == b.guidance_scale && a.seed == b.seed;
+           a.guidance_scale == b.guidance_scale && a.seed == b.seed && a.top_p == b.top_p;
 }
 
 void drop_graph(ptts_engine* e) {
@@ -803,8 +804,9 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
         g.epi = EPI_ROWMAJOR; g.out = e->enc_h; g.ldo = D; g.bias = e->enc_proj_bias; g.rowmask = attention_mask;
         PTTS_TRY(launch_gemm(e, g, s));
         enc_h = e->enc_h;
-    } else {
-        return fail(PTTS_E_UNSUPPORTED, "enc_hidden == hidden (no enc_to_dec_proj) is not wired yet");
+    } else {   // no enc_to_dec_proj (M:2010-2014 is skipped), only the mask multiply
+        HIP_TRY(rowmask_mul_launch(enc_states, attention_mask, e->enc_h, M, D, s));
+        enc_h = e->enc_h;
     }
     // cross K/V of every layer into the cross pool (M:295-298)
     for (int l = 0; l < c.layers; ++l) {

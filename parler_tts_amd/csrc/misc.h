@@ -28,7 +28,7 @@ struct SelectArgs {
     float* probs = nullptr;              // [rows][V] or null
     int pad = 0, eos = 0;
     int do_sample = 0, top_k = 0;
-    float temperature = 1.0f, guidance = 1.0f;
+    float temperature = 1.0f, guidance = 1.0f, top_p = 1.0f;
     unsigned long long seed = 0;
 };
 
@@ -40,5 +40,6 @@ hipError_t advance_launch(StepState* st, int* unf_count, int L, hipStream_t s);
 hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,
                               int L, int col, hipStream_t s);
 hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s);
+hipError_t rowmask_mul_launch(const float* x, const int* rowmask, float* y, int rows, int D, hipStream_t s);
 hipError_t t5_embed_launch(const long long* ids, const void* table, float* x, int rows, int D, int dtype, hipStream_t s);
 hipError_t rmsnorm_rows_launch(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s);

@@ -189,6 +189,44 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             if (a.probs) a.probs[(size_t)row * a.V + v] = p;
         }
         __syncthreads();
+        // ---- top-p (TopPLogitsWarper, applied after top-k): in ascending order of probability, drop the
+        //      tokens whose cumulative probability is <= 1 - top_p; the most probable token always stays ----
+        if (a.top_p < 1.0f) {
+            float* keep = sv + a.V;                     // second LDS row
+            float pmax = 0.f;
+            for (int v = tid; v < V; v += 256) pmax = fmaxf(pmax, sv[v]);
+            pmax = wave_max(pmax);
+            if (lane == 0) wv[w] = pmax;
+            __syncthreads();
+            pmax = fmaxf(fmaxf(wv[0], wv[1]), fmaxf(wv[2], wv[3]));
+            __syncthreads();
+            for (int v = tid; v < V; v += 256) {
+                const float pv = sv[v];
+                float k = 0.f;
+                if (pv > 0.f) {
+                    float c = 0.f;                      // cumulative probability up to and including v
+                    for (int u = 0; u < V; ++u) {
+                        const float pu = sv[u];
+                        if (pu < pv || (pu == pv && u <= v)) c += pu;
+                    }
+                    k = (c > 1.0f - a.top_p || pv == pmax) ? 1.f : 0.f;
+                }
+                keep[v] = k;
+            }
+            __syncthreads();
+            float s2 = 0.f;
+            for (int v = tid; v < V; v += 256) { const float pk = sv[v] * keep[v]; sv[v] = pk; s2 += pk; }
+            s2 = wave_sum(s2);
+            if (lane == 0) wv[w] = s2;
+            __syncthreads();
+            s2 = (wv[0] + wv[1]) + (wv[2] + wv[3]);
+            for (int v = tid; v < V; v += 256) {
+                const float pk = sv[v] / s2;
+                sv[v] = pk;
+                if (a.probs) a.probs[(size_t)row * a.V + v] = pk;
+            }
+            __syncthreads();
+        }
         // ---- inverse CDF, index order (one thread: V ~ 1e3) ----
         if (tid == 0) {
             float u = philox_uniform(a.seed, (uint32_t)row, (uint32_t)a.state->step_count);
@@ -264,6 +302,13 @@ __global__ void build_bias_kernel(const int* mask, float* bias, int B, int n_mas
     bias[i] = v;
 }
 
+// encoder states pass through unprojected when the widths match: enc_h = enc * attention_mask (M:2016-2017)
+__global__ void rowmask_mul_kernel(const float* x, const int* rowmask, float* y, int rows, int D) {
+    const int r = blockIdx.x;
+    const float m = (float)rowmask[r];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) y[(size_t)r * D + d] = x[(size_t)r * D + d] * m;
+}
+
 __global__ void t5_embed_kernel(const long long* ids, const void* table, float* x, int D, int is_bf16) {
     const int r = blockIdx.x;
     const long long tok = ids[r];
@@ -306,7 +351,7 @@ hipError_t advance_prompt_launch(StepState* st, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t select_launch(const SelectArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(select_kernel, dim3(a.rows), dim3(256), (size_t)a.V * sizeof(float), s, a);
+    hipLaunchKernelGGL(select_kernel, dim3(a.rows), dim3(256), (size_t)2 * a.V * sizeof(float), s, a);
     return hipGetLastError();
 }
 hipError_t advance_launch(StepState* st, int* unf_count, int L, hipStream_t s) {
@@ -322,6 +367,10 @@ hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern
 hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s) {
     int n = B * ld_bias;
     hipLaunchKernelGGL(build_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, bias, B, n_mask, ld_bias);
+    return hipGetLastError();
+}
+hipError_t rowmask_mul_launch(const float* x, const int* rowmask, float* y, int rows, int D, hipStream_t s) {
+    hipLaunchKernelGGL(rowmask_mul_kernel, dim3(rows), dim3(256), 0, s, x, rowmask, y, rows, D);
     return hipGetLastError();
 }
 hipError_t t5_embed_launch(const long long* ids, const void* table, float* x, int rows, int D, int dtype, hipStream_t s) {

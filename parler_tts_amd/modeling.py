@@ -432,8 +432,6 @@ class ParlerTTSForConditionalGeneration:
             raise ValueError(f"num_return_sequences has to be 1 when doing greedy search, but is {gen.num_return_sequences}.")
         if sample and gen.num_return_sequences > 1:
             raise NotImplementedError("num_return_sequences > 1: repeat the batch rows instead")
-        if sample and gen.top_p is not None and gen.top_p < 1.0:
-            raise NotImplementedError("top_p warping is not implemented on device (top_k and temperature are)")
 
         eng = self.engine(B_eff, T, P, L)
         import time as _time
@@ -474,6 +472,7 @@ class ParlerTTSForConditionalGeneration:
         sp.temperature = float(gen.temperature if gen.temperature is not None else 1.0)
         sp.top_k = int(gen.top_k or 0)
         sp.guidance_scale = float(gen.guidance_scale) if use_cfg else 1.0
+        sp.top_p = float(gen.top_p) if (gen.top_p is not None and 0.0 < gen.top_p < 1.0) else 1.0
         sp.seed = int(gen.seed if gen.seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len)
         t_dec = _tick()

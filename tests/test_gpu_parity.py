@@ -588,3 +588,51 @@ def test_scaled_decoder_config_bf16(hip):
     top2 = torch.topk(want, 2, dim=-1)[0]
     safe = (top2[..., 0] - top2[..., 1]) > 0.05
     assert (got.argmax(-1)[safe] == want.argmax(-1)[safe]).float().mean() > 0.97
+
+
+def test_top_p_warper_matches_oracle(hip):
+    """temperature -> top-k -> top-p, teacher-forced along the reference's sampled path"""
+    from oracle import cpu_ref
+    from parler_tts_amd import _hip
+
+    f, meta = load_case("tiny_sample")
+    cfg, model = model_for("tiny_sample", meta, "fp32")
+    desc, amask, prompt, _ = case_inputs(f)
+    K, B, L = cfg.decoder.num_codebooks, desc.shape[0], int(f["max_length"])
+    eng = model.engine(B, desc.shape[1], prompt.shape[1], L)
+    gold = torch.from_numpy(f["raw_ids"])
+    _fresh_prefill(eng, cfg, f, amask, prompt, L)
+    sp = _hip.PttsSampling(1, 0.7, 40, 1.0, 3, 0.8)
+    probs = []
+    for s in range(6):
+        eng.set_forced_tokens(gold[:, s + 1])
+        eng.decode_steps(1, sp)
+        probs.append(eng.last_logits(B * K, probs=True).cpu())
+    eng.set_forced_tokens(None)
+    p = torch.stack(probs)
+    ref = torch.softmax(cpu_ref.warp_logits(torch.from_numpy(f["step_logits"][:6]), 0.7, 40, 0.8), dim=-1)
+    # The synthetic heads tie 64 logits at exactly 0 and torch.sort orders ties arbitrarily (the kernel uses
+    # index order), so WHICH of the tied tokens survive is not defined by the reference; how many survive and
+    # with what probabilities is: compare the sorted probability vectors.
+    ps, rs = p.sort(-1, descending=True)[0], ref.sort(-1, descending=True)[0]
+    assert torch.equal((ps > 0).sum(-1), (rs > 0).sum(-1))
+    assert (ps - rs).abs().max() < 1e-5
+    untied = torch.from_numpy(f["step_logits"][:6]) != 0          # outside the tie, membership must agree exactly
+    assert torch.equal((p > 0)[untied], (ref > 0)[untied])
+    assert ((p > 0).sum(-1) < 40).any()          # top-p actually removed something beyond top-k
+    assert torch.allclose(p.sum(-1), torch.ones(p.shape[:2]), atol=1e-5)
+    # and it is reachable through generate()
+    model.generate(encoder_outputs=(torch.from_numpy(f["enc_t5"]),), attention_mask=amask, prompt_input_ids=prompt,
+                   do_sample=True, top_k=40, top_p=0.8, temperature=0.7, max_length=L, seed=5, return_raw_ids=True)
+
+
+def test_decoder_without_enc_to_dec_proj(hip):
+    """text-encoder width == decoder width: no enc_to_dec_proj (M:2010-2014 skipped), only the mask multiply"""
+    from parler_tts_amd.configuration import tiny_config
+    from parler_tts_amd.weights import all_keys, synthetic_state_dict
+
+    cfg = tiny_config(enc_d=128)
+    assert "enc_to_dec_proj.weight" not in all_keys(cfg)
+    sd = synthetic_state_dict(cfg, seed=13, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+    got, want, _, _ = _oracle_vs_engine(cfg, sd, "fp32", B=3, T=7, P=4, L=14, seed=6, steps=10)
+    assert (got - want).abs().max() < 2e-4
