@@ -134,8 +134,11 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
+    // H2 = 2: the workgroup covers both 16-row halves of the m-tile.  H2 = 1 (fragment input only): one half per
+    // workgroup; the two halves of a feature block sit 8 apart in the linear block id, i.e. on the same XCD, so
+    // the second read of the block's weights is served by that XCD's L2.
     // KI: float4 per lane per activation row held in registers by the staged prologue (K chunk <= 256*KI)
     typedef typename P::elem_t elem_t;
     typedef Tile<P> T;
@@ -148,7 +151,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     constexpr int RB = RPW < 4 ? RPW : 4;                // rows normalised together (ILP across rows)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nb0 = blockIdx.x * NB;
+    int nb0 = blockIdx.x * NB, hsel = 0;
+    if (H2 == 1) {
+        const int id = blockIdx.x;
+        nb0 = (((id >> 4) << 3) + (id & 7)) * NB;
+        hsel = (id >> 3) & 1;
+        if (nb0 * 16 >= a.N) return;            // padding blocks of the last group of 8
+    }
     const int m0 = blockIdx.y * 32;
     const int K = a.K;
     const int ksteps = K / KSTEP;
@@ -169,8 +178,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // read-modify-write at the end does not start with a cold load
     float4 xres = make_float4(0, 0, 0, 0);
     bool have_res = false;
-    if (a.epi == EPI_RESIDUAL && tid < NB * 128) {
-        const int ln = tid & 63, hh = (tid >> 6) & 1, ii = tid >> 7;
+    if (a.epi == EPI_RESIDUAL && tid < NB * 64 * H2) {
+        const int ln = tid & 63, hh = H2 == 2 ? ((tid >> 6) & 1) : hsel, ii = H2 == 2 ? (tid >> 7) : (tid >> 6);
         const int row = m0 + 16 * hh + (ln & 15), n = (nb0 + ii) * 16 + 4 * (ln >> 4);
         if (row < a.M && n < a.N) { xres = *reinterpret_cast<const float4*>(a.out + (size_t)row * a.ldo + n); have_res = true; }
     }
@@ -310,14 +319,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                         b1 = T::load_lds(xs, ld, 16 + (lane & 15), ks - c0, lane);
                     } else {
                         const elem_t* xf = reinterpret_cast<const elem_t*>(a.xfrag) + (size_t)blockIdx.y * 32 * K +
-                                           (size_t)(ks * 2) * TILE + lane * EPL;
+                                           (size_t)(ks * 2 + hsel) * TILE + lane * EPL;
                         b0 = T::load_global(xf);
-                        b1 = T::load_global(xf + TILE);
+                        if (H2 == 2) b1 = T::load_global(xf + TILE);
                     }
 #pragma unroll
                     for (int i = 0; i < NB; ++i) {
                         T::mma(wt[u][i], b0, acc[i][0]);
-                        T::mma(wt[u][i], b1, acc[i][1]);
+                        if (H2 == 2) T::mma(wt[u][i], b1, acc[i][1]);
                     }
                 }
             }
@@ -330,27 +339,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         redv[((w * NB + i) * 2 + 0) * 64 + lane] = acc[i][0];
-        redv[((w * NB + i) * 2 + 1) * 64 + lane] = acc[i][1];
+        if (H2 == 2) redv[((w * NB + i) * 2 + 1) * 64 + lane] = acc[i][1];
     }
     __syncthreads();
     const bool gated = (a.epi == EPI_GATED_FRAG);
-    const int items = gated ? 128 : NB * 128;
+    const int items = gated ? 128 : NB * 64 * H2;
     for (int t = tid; t < items; t += NW * 64) {
-        const int ln = t & 63, h = (t >> 6) & 1, i = gated ? 0 : (t >> 7);
+        const int ln = t & 63, h = H2 == 2 ? ((t >> 6) & 1) : 0, i = gated ? 0 : (H2 == 2 ? (t >> 7) : (t >> 6));
         f32x4 s = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
         for (int ww = 0; ww < NW; ++ww) {
             f32x4 p = redv[((ww * NB + i) * 2 + h) * 64 + ln];
             s += p;
             if (gated) s1 += redv[((ww * NB + 1) * 2 + h) * 64 + ln];
         }
-        const int row = m0 + 16 * h + (ln & 15);
+        const int row = m0 + 16 * (H2 == 2 ? h : hsel) + (ln & 15);
         if (row >= a.M) continue;
         const int n = gated ? blockIdx.x * 16 + 4 * (ln >> 4) : (nb0 + i) * 16 + 4 * (ln >> 4);
         epilogue<P>(a, row, n, s, s1, xres, have_res && t == tid);
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2>
 hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int KC = 256 * KI;
     constexpr int PAD = 16 / (int)sizeof(typename P::elem_t);
@@ -359,7 +368,8 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     const size_t red_bytes = (size_t)NW * NB * 2 * 64 * 16;
     if (lds < red_bytes) lds = red_bytes;
     dim3 grid((a.N + 16 * NB - 1) / (16 * NB), (a.M + 31) / 32);
-    auto kern = gemm_kernel<P, NW, NB, STAGE, KI>;
+    if (H2 == 1) grid.x = ((grid.x + 7) / 8) * 16;     // groups of 8 blocks x 2 halves
+    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -384,6 +394,13 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     }
     // fragment input: enough K-split that a wave streams <= ~8 tiles in one burst
     const int nw = ksteps > 64 ? 16 : (ksteps > 16 ? 8 : 4);   // <= 8 (K<=2048 bf16) / 4 tiles in flight per wave
+    // few feature blocks and more than 16 live rows: one 16-row half per workgroup doubles the busy CUs
+    const bool halves = a.N <= 2048 && a.M > 16 && a.epi != EPI_GATED_FRAG;
+    if (halves) {
+        if (nw == 16) return launch_one<P, 16, 1, false, 1, 1>(a, stream);
+        if (nw == 8) return launch_one<P, 8, 1, false, 1, 1>(a, stream);
+        return launch_one<P, 4, 1, false, 1, 1>(a, stream);
+    }
     if (nw == 16) return launch_one<P, 16, 1, false, 1>(a, stream);
     if (nw == 8) return launch_one<P, 8, 1, false, 1>(a, stream);
     return launch_one<P, 4, 1, false, 1>(a, stream);
@@ -391,7 +408,7 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
 
 template <typename P, int NW, int NB, int KI>
 hipError_t allow_big_lds() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<P, NW, NB, true, KI>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<P, NW, NB, true, KI, 2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <typename P>
