@@ -52,9 +52,17 @@ struct Packed {
     int N = 0, K = 0;
 };
 
+// LayerNorm-folded copy of a projection that follows a LayerNorm: diag(gamma).W in packed layout + the two
+// per-feature constants of gemm.h's `fold` path.  Rebuilt from the loaded tensors whenever one of them changes.
+struct Folded {
+    void* w = nullptr;
+    float *c1 = nullptr, *c2 = nullptr;
+};
+
 struct DecLayer {
     Packed qkv, o, cq, ckv, co, fc1, fc2;
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
+    Folded qkv_f, cq_f, fc1_f;
 };
 struct T5Layer {
     Packed qkv, o, wi, wo;
@@ -86,6 +94,9 @@ struct ptts_engine {
     // decoder weights
     std::vector<DecLayer> layers;
     Packed heads, enc_proj;
+    Folded heads_f;
+    bool fold_ln = false;      // LayerNorm applied after the MFMA on gamma-folded weights (default for bf16)
+    bool fold_dirty = true;    // a tensor arrived since the folded copies were built
     float *lnf_g = nullptr, *lnf_b = nullptr, *enc_proj_bias = nullptr;
     void *embed_tokens = nullptr, *pos_table = nullptr, *embed_prompts = nullptr;
     // T5
@@ -100,6 +111,7 @@ struct ptts_engine {
     int mtiles = 1;
     float *x = nullptr, *q = nullptr, *logits = nullptr, *probs = nullptr, *enc_h = nullptr;
     void *attn_frag = nullptr, *mlp_frag = nullptr;
+    void* x_frag = nullptr;    // fragment-layout copy of `x` (weight dtype), written next to every update of `x`
     float *self_bias = nullptr, *cross_bias = nullptr;
     int s_cap = 0;
     bool has_self_bias = false;
@@ -230,6 +242,35 @@ int load_table(ptts_engine* e, void** dst, size_t total, size_t off, size_t n, c
 
 #define DBG_GATE(e) do { if ((e)->dbg_stop >= 0 && (e)->dbg_count++ >= (e)->dbg_stop) return PTTS_OK; } while (0)
 
+// switch a LayerNorm-prologue projection to its folded form (fragment input = raw residual rows)
+void use_fold(const ptts_engine* e, GemmArgs* g, const Folded& f) {
+    if (!e->fold_ln) return;
+    g->W = f.w; g->pro = PRO_FRAG; g->xfrag = e->x_frag; g->x = nullptr; g->fold = 1; g->c1 = f.c1; g->c2 = f.c2;
+}
+
+int fold_one(ptts_engine* e, const Packed& w, const float* gamma, const float* beta, Folded* f, hipStream_t s) {
+    if (!f->w) {
+        PTTS_TRY(dev_alloc(e, &f->w, (size_t)w.N * w.K * e->esz));
+        PTTS_TRY(dev_alloc(e, (void**)&f->c1, (size_t)w.N * sizeof(float)));
+        PTTS_TRY(dev_alloc(e, (void**)&f->c2, (size_t)w.N * sizeof(float)));
+    }
+    HIP_TRY(fold_layernorm_launch(w.ptr, f->w, gamma, beta, f->c1, f->c2, w.N, w.K, e->dt, s));
+    return PTTS_OK;
+}
+
+// (re)build every folded projection on the stream the decoder is about to run on
+int refresh_folds(ptts_engine* e, hipStream_t s) {
+    if (!e->fold_ln || !e->fold_dirty) return PTTS_OK;
+    for (auto& w : e->layers) {
+        PTTS_TRY(fold_one(e, w.qkv, w.ln1_g, w.ln1_b, &w.qkv_f, s));
+        PTTS_TRY(fold_one(e, w.cq, w.ln2_g, w.ln2_b, &w.cq_f, s));
+        PTTS_TRY(fold_one(e, w.fc1, w.ln3_g, w.ln3_b, &w.fc1_f, s));
+    }
+    PTTS_TRY(fold_one(e, e->heads, e->lnf_g, e->lnf_b, &e->heads_f, s));
+    e->fold_dirty = false;
+    return PTTS_OK;
+}
+
 // ---- one decoder layer stack over B_eff rows at the current position (decode token or prompt token) ----
 int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
     const ptts_config& c = e->cfg;
@@ -242,6 +283,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         g = GemmArgs();
         g.W = w.qkv.ptr; g.N = 3 * D; g.K = D; g.M = M;
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.eps = 1e-5f;
+        use_fold(e, &g, w.qkv_f);
         g.epi = EPI_QKV_SELF; g.out = e->q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
         g.state = e->state; g.D = D;
         DBG_GATE(e);
@@ -264,13 +306,14 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         // out_proj + residual (M:380, M:460)
         g = GemmArgs();
         g.W = w.o.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->x_frag : nullptr;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         // LN2 + cross-attention query (M:467-471)
         g = GemmArgs();
         g.W = w.cq.ptr; g.N = D; g.K = D; g.M = M;
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.eps = 1e-5f;
+        use_fold(e, &g, w.cq_f);
         g.epi = EPI_Q_SCALE; g.out = e->q; g.ldo = D; g.scale = scale;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
@@ -283,19 +326,20 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
         g = GemmArgs();
         g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->x_frag : nullptr;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         // LN3 + fc1 + GELU(erf) -> fragments ; fc2 + residual (M:486-492)
         g = GemmArgs();
         g.W = w.fc1.ptr; g.N = F; g.K = D; g.M = M;
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.eps = 1e-5f;
+        use_fold(e, &g, w.fc1_f);
         g.epi = EPI_ACT_FRAG; g.act = ACT_GELU; g.ofrag = e->mlp_frag; g.ldo = F;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         g = GemmArgs();
         g.W = w.fc2.ptr; g.N = D; g.K = F; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->mlp_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->x_frag : nullptr;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
     }
@@ -307,6 +351,7 @@ EmbedArgs embed_args(ptts_engine* e) {
     a.tables = e->embed_tokens; a.rows = e->cfg.vocab + 1; a.K = e->cfg.codebooks; a.D = e->cfg.hidden;
     a.pos_table = e->pos_table; a.tok_in = e->tok_in; a.prompt_table = e->embed_prompts;
     a.prompt_ids = e->prompt_ids; a.P = e->P; a.state = e->state; a.x = e->x;
+    a.xfrag = e->fold_ln ? e->x_frag : nullptr;
     return a;
 }
 
@@ -326,6 +371,7 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
     GemmArgs g;
     g.W = e->heads.ptr; g.N = c.codebooks * e->Vp; g.K = c.hidden; g.M = e->B_eff;
     g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = c.hidden; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.eps = 1e-5f;
+    use_fold(e, &g, e->heads_f);
     g.epi = EPI_ROWMAJOR; g.out = e->logits; g.ldo = c.codebooks * e->Vp;
     PTTS_TRY(launch_gemm(e, g, s));
     SelectArgs sa;
@@ -503,6 +549,8 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->layers.resize(cfg->layers);
     e->t5.resize(cfg->t5_layers > 0 ? cfg->t5_layers : 0);
     e->no_graph = getenv("PTTS_NO_GRAPH") != nullptr;
+    e->fold_ln = cfg->dtype == PTTS_DTYPE_BF16;
+    if (const char* v = getenv("PTTS_LN_FOLD")) e->fold_ln = atoi(v) != 0;
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     if (cfg->dac_hidden > 0) {
         if (cfg->dac_n_up <= 0 || cfg->dac_n_up > 8 || cfg->dac_hidden % (16 << cfg->dac_n_up) != 0 || cfg->dac_latent % 16 != 0) {
@@ -556,6 +604,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->x, sizeof(float) * rows * D);
     A(e->q, sizeof(float) * rows * D);
     A(e->attn_frag, e->esz * rows * D);
+    A(e->x_frag, e->esz * rows * D);
     A(e->mlp_frag, e->esz * rows * F);
     A(e->logits, sizeof(float) * rows * K * e->Vp);
     A(e->probs, sizeof(float) * rows * K * e->Vp);
@@ -587,6 +636,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     if (he == hipSuccess) he = hipMemset(e->state, 0, sizeof(StepState));
     if (he == hipSuccess) he = hipMemset(e->unf_count, 0, 4 * sizeof(int));
     if (he == hipSuccess) he = hipMemset(e->attn_frag, 0, e->esz * rows * D);
+    if (he == hipSuccess) he = hipMemset(e->x_frag, 0, e->esz * rows * D);
     if (he == hipSuccess) he = hipMemset(e->mlp_frag, 0, e->esz * rows * F);
     if (he == hipSuccess) he = hipMemset(e->x, 0, sizeof(float) * rows * D);
     if (he != hipSuccess) { ptts_destroy(e); return fail(PTTS_E_HIP, "init copies failed: %s", hipGetErrorString(he)); }
@@ -685,7 +735,7 @@ int ptts_load_tensor(ptts_engine* e, const char* cname, const float* data, const
         return PTTS_OK;  // tied T5 embedding alias
     } else known = false;
     if (!known) return fail(PTTS_E_INVALID, "unknown tensor name '%s'", cname);
-    if (rc == PTTS_OK) e->loaded.insert(name);
+    if (rc == PTTS_OK) { e->loaded.insert(name); e->fold_dirty = true; }
     if (rc == PTTS_OK) rc = leave_stream(e, stream, s);
     return rc;
 }
@@ -789,6 +839,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     PTTS_TRY(enter_stream(e, stream, &s));
     e->dbg_count = 0;
     drop_graph(e);
+    PTTS_TRY(refresh_folds(e, s));
     e->B = B; e->B_eff = B_eff; e->T = T; e->P = P; e->L = L;
     e->pattern = (const long long*)pattern; e->raw_ids = (long long*)raw_ids; e->prompt_ids = (const long long*)prompt_ids;
     const int D = c.hidden, M = B_eff * T;

@@ -19,6 +19,11 @@ struct GemmArgs {
     const float* gamma = nullptr;
     const float* beta = nullptr;
     float eps = 1e-5f;
+    // folded LayerNorm (PRO_FRAG only): `xfrag` holds the RAW residual rows, W is diag(gamma).W, and the
+    // normalisation is applied after the MFMA: y = rstd * (x.W' - mean * c1) + c2   (see fold_layernorm_launch)
+    int fold = 0;
+    const float* c1 = nullptr;    // [N] sum_k W'[n][k]
+    const float* c2 = nullptr;    // [N] sum_k beta[k] * W[n][k]
     // epilogue
     int epi = EPI_ROWMAJOR;
     float* out = nullptr;
@@ -26,6 +31,7 @@ struct GemmArgs {
     const float* bias = nullptr;
     const int* rowmask = nullptr;
     void* ofrag = nullptr;
+    void* xfrag_out = nullptr;    // EPI_RESIDUAL: also store the updated rows as fragments [(M+31)/32][32*ldo]
     int act = ACT_NONE;
     float scale = 1.0f;
     KVPool pool = {};
@@ -40,4 +46,8 @@ int gemm_validate(const GemmArgs& a, int dtype);
 hipError_t gemm_launch(const GemmArgs& a, int dtype, hipStream_t stream);
 hipError_t pack_weight_launch(const float* W, void* out, int N, int K, int n_off, int n_stride, int dtype,
                               hipStream_t stream);
+// Wf = diag(gamma).W re-rounded to the weight dtype (both in packed layout), c1[n] = sum_k Wf[n][k],
+// c2[n] = sum_k beta[k] * W[n][k]; N is the padded row count of the packed matrix
+hipError_t fold_layernorm_launch(const void* W, void* Wf, const float* gamma, const float* beta, float* c1, float* c2,
+                                 int N, int K, int dtype, hipStream_t stream);
 hipError_t convert_launch(const float* src, void* dst, size_t n, int dtype, hipStream_t stream);

@@ -50,6 +50,10 @@ template <> struct Tile<PBF16> {
     static __device__ inline wfrag load_lds(const uint16_t* xs, int ld, int r, int ks_local, int lane) {
         return *reinterpret_cast<const bf16x8*>(xs + (size_t)r * ld + ks_local * 32 + 8 * (lane >> 4));
     }
+    static __device__ inline wfrag ones() {
+        const __bf16 o = (__bf16)1.0f;
+        return wfrag{o, o, o, o, o, o, o, o};
+    }
 };
 template <> struct Tile<PF32> {
     typedef f32x4 wfrag;
@@ -65,6 +69,7 @@ template <> struct Tile<PF32> {
         v[0] = p[0]; v[1] = p[4]; v[2] = p[8]; v[3] = p[12];
         return v;
     }
+    static __device__ inline wfrag ones() { return wfrag{1.f, 1.f, 1.f, 1.f}; }
 };
 
 template <typename P>
@@ -91,6 +96,12 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
             float4 x = have_res ? xres : *o;     // the residual slice was requested at kernel entry
             x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
             *o = x;
+            if (a.xfrag_out) {   // the next LayerNorm-folded projection reads the raw rows as B fragments
+                elem_t* of = reinterpret_cast<elem_t*>(a.xfrag_out) + (size_t)(row >> 5) * 32 * a.ldo;
+                const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) of[frag_off<P>(row & 31, n + r)] = to_elem<P>(xv[r]);
+            }
             break;
         }
         case EPI_Q_SCALE: {
@@ -134,8 +145,11 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
+    // FOLD (fragment input, NB = 1): the fragments are the raw residual rows and W carries the LayerNorm gain.
+    // Row statistics come from the matrix cores: ones . x gives sum(x) in every accumulator row, x . x^T has
+    // sum(x^2) on its diagonal (A and B operands of the 16x16 MFMA share one register layout).
     // H2 = 2: the workgroup covers both 16-row halves of the m-tile.  H2 = 1 (fragment input only): one half per
     // workgroup; the two halves of a feature block sit 8 apart in the linear block id, i.e. on the same XCD, so
     // the second read of the block's weights is served by that XCD's L2.
@@ -183,6 +197,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         const int row = m0 + 16 * hh + (ln & 15), n = (nb0 + ii) * 16 + 4 * (ln >> 4);
         if (row < a.M && n < a.N) { xres = *reinterpret_cast<const float4*>(a.out + (size_t)row * a.ldo + n); have_res = true; }
     }
+    float4 c1v = make_float4(0, 0, 0, 0), c2v = make_float4(0, 0, 0, 0);
+    if (FOLD && tid < 64 * H2) {
+        const int n = nb0 * 16 + 4 * ((tid & 63) >> 4);
+        c1v = *reinterpret_cast<const float4*>(a.c1 + n);
+        c2v = *reinterpret_cast<const float4*>(a.c2 + n);
+    }
+    f32x4 accS[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, accG[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    const typename T::wfrag ones = T::ones();
     const int cstep = STAGE ? KC / KSTEP : ksteps;   // only the LDS-staged path needs K chunks
 
     // first burst of this wave's weight tiles: issued before the prologue so HBM latency hides under it
@@ -328,6 +350,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                         T::mma(wt[u][i], b0, acc[i][0]);
                         if (H2 == 2) T::mma(wt[u][i], b1, acc[i][1]);
                     }
+                    if (FOLD) {
+                        T::mma(ones, b0, accS[0]);
+                        T::mma(b0, b0, accG[0]);
+                        if (H2 == 2) { T::mma(ones, b1, accS[1]); T::mma(b1, b1, accG[1]); }
+                    }
                 }
             }
         }
@@ -341,6 +368,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         redv[((w * NB + i) * 2 + 0) * 64 + lane] = acc[i][0];
         if (H2 == 2) redv[((w * NB + i) * 2 + 1) * 64 + lane] = acc[i][1];
     }
+    // per wave and 16-row half: 16 x sum(x) (accumulator row 0) and 16 x sum(x^2) (the Gram diagonal)
+    float* stat = red + (size_t)NW * NB * 2 * 64 * 4;    // [NW][2 halves][2][16]
+    if (FOLD) {
+        const int b = lane & 15;
+#pragma unroll
+        for (int h = 0; h < H2; ++h) {
+            if (lane < 16) stat[((w * 2 + h) * 2 + 0) * 16 + b] = accS[h][0];
+            if ((lane >> 4) == (b >> 2)) {
+                const f32x4 g = accG[h];
+                const int r = b & 3;
+                stat[((w * 2 + h) * 2 + 1) * 16 + b] = r == 0 ? g[0] : (r == 1 ? g[1] : (r == 2 ? g[2] : g[3]));
+            }
+        }
+    }
     __syncthreads();
     const bool gated = (a.epi == EPI_GATED_FRAG);
     const int items = gated ? 128 : NB * 64 * H2;
@@ -353,23 +394,38 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             if (gated) s1 += redv[((ww * NB + 1) * 2 + h) * 64 + ln];
         }
         const int row = m0 + 16 * (H2 == 2 ? h : hsel) + (ln & 15);
+        if (FOLD) {
+            float sx = 0.f, sq = 0.f;
+            for (int ww = 0; ww < NW; ++ww) {
+                sx += stat[((ww * 2 + h) * 2 + 0) * 16 + (ln & 15)];
+                sq += stat[((ww * 2 + h) * 2 + 1) * 16 + (ln & 15)];
+            }
+            const float invK = 1.0f / (float)K;
+            const float mean = sx * invK;
+            const float var = fmaxf(sq * invK - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + a.eps);
+            s[0] = rstd * (s[0] - mean * c1v.x) + c2v.x;
+            s[1] = rstd * (s[1] - mean * c1v.y) + c2v.y;
+            s[2] = rstd * (s[2] - mean * c1v.z) + c2v.z;
+            s[3] = rstd * (s[3] - mean * c1v.w) + c2v.w;
+        }
         if (row >= a.M) continue;
         const int n = gated ? blockIdx.x * 16 + 4 * (ln >> 4) : (nb0 + i) * 16 + 4 * (ln >> 4);
         epilogue<P>(a, row, n, s, s1, xres, have_res && t == tid);
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false>
 hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int KC = 256 * KI;
     constexpr int PAD = 16 / (int)sizeof(typename P::elem_t);
     int kc = STAGE ? (a.K < KC ? a.K : KC) : 0;
     size_t lds = STAGE ? ((((size_t)32 * (kc + PAD) * sizeof(typename P::elem_t)) + 15) & ~(size_t)15) : 0;
-    const size_t red_bytes = (size_t)NW * NB * 2 * 64 * 16;
+    const size_t red_bytes = (size_t)NW * NB * 2 * 64 * 16 + (FOLD ? (size_t)NW * 2 * 2 * 16 * 4 : 0);
     if (lds < red_bytes) lds = red_bytes;
     dim3 grid((a.N + 16 * NB - 1) / (16 * NB), (a.M + 31) / 32);
     if (H2 == 1) grid.x = ((grid.x + 7) / 8) * 16;     // groups of 8 blocks x 2 halves
-    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2>;
+    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -396,6 +452,16 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     const int nw = ksteps > 64 ? 16 : (ksteps > 16 ? 8 : 4);   // <= 8 (K<=2048 bf16) / 4 tiles in flight per wave
     // few feature blocks and more than 16 live rows: one 16-row half per workgroup doubles the busy CUs
     const bool halves = a.N <= 2048 && a.M > 16 && a.epi != EPI_GATED_FRAG;
+    if (a.fold) {
+        if (halves) {
+            if (nw == 16) return launch_one<P, 16, 1, false, 1, 1, true>(a, stream);
+            if (nw == 8) return launch_one<P, 8, 1, false, 1, 1, true>(a, stream);
+            return launch_one<P, 4, 1, false, 1, 1, true>(a, stream);
+        }
+        if (nw == 16) return launch_one<P, 16, 1, false, 1, 2, true>(a, stream);
+        if (nw == 8) return launch_one<P, 8, 1, false, 1, 2, true>(a, stream);
+        return launch_one<P, 4, 1, false, 1, 2, true>(a, stream);
+    }
     if (halves) {
         if (nw == 16) return launch_one<P, 16, 1, false, 1, 1>(a, stream);
         if (nw == 8) return launch_one<P, 8, 1, false, 1, 1>(a, stream);
@@ -408,7 +474,7 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
 
 template <typename P, int NW, int NB, int KI>
 hipError_t allow_big_lds() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<P, NW, NB, true, KI, 2>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<P, NW, NB, true, KI, 2, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <typename P>
@@ -437,6 +503,35 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, typename P::elem
     out[wpack_off<P>(dn, k, Kp)] = to_elem<P>(W[idx]);
 }
 
+// LayerNorm fold, one wave per 16-row block of the packed matrix (runs once per weight set)
+template <typename P>
+__global__ __launch_bounds__(64) void fold_ln_kernel(const typename P::elem_t* __restrict__ W, typename P::elem_t* __restrict__ Wf,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ c1, float* __restrict__ c2, int K) {
+    constexpr int KSTEP = P::KSTEP, EPL = P::EPL, TILE = 64 * EPL;
+    __shared__ float sh[2][64];
+    const int nb = blockIdx.x, lane = threadIdx.x, ksteps = K / KSTEP;
+    float s1 = 0.f, s2 = 0.f;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const size_t base = ((size_t)nb * ksteps + ks) * TILE + (size_t)lane * EPL;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int k = P::IS_BF16 ? ks * KSTEP + 8 * (lane >> 4) + j : ks * KSTEP + 4 * j + (lane >> 4);
+            const float w = from_elem<P>(W[base + j]);
+            const typename P::elem_t wf = to_elem<P>(gamma[k] * w);
+            Wf[base + j] = wf;
+            s1 += from_elem<P>(wf);
+            s2 += beta[k] * w;
+        }
+    }
+    sh[0][lane] = s1; sh[1][lane] = s2;
+    __syncthreads();
+    if (lane < 16) {
+        c1[nb * 16 + lane] = (sh[0][lane] + sh[0][lane + 16]) + (sh[0][lane + 32] + sh[0][lane + 48]);
+        c2[nb * 16 + lane] = (sh[1][lane] + sh[1][lane + 16]) + (sh[1][lane + 32] + sh[1][lane + 48]);
+    }
+}
+
 template <typename P>
 __global__ void convert_kernel(const float* __restrict__ src, typename P::elem_t* dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -456,6 +551,7 @@ int gemm_validate(const GemmArgs& a, int dtype) {
         if ((a.pro == PRO_LAYERNORM || a.pro == PRO_RMSNORM) && (a.K > kc || !a.gamma)) return -5;
         if (a.pro == PRO_LAYERNORM && !a.beta) return -5;
     } else if (!a.xfrag) return -6;
+    if (a.fold && (a.pro != PRO_FRAG || !a.c1 || !a.c2 || a.epi == EPI_GATED_FRAG)) return -10;
     if (a.epi == EPI_GATED_FRAG && a.N % 32 != 0) return -7;
     if ((a.epi == EPI_RESIDUAL || a.epi == EPI_Q_SCALE || a.epi == EPI_QKV_SELF) && (a.ldo % 4 != 0)) return -8;
     if ((a.epi == EPI_QKV_SELF || a.epi == EPI_KV_CROSS) && (a.D % 64 != 0 || a.N % a.D != 0)) return -9;
@@ -483,6 +579,17 @@ hipError_t pack_weight_launch(const float* W, void* out, int N, int K, int n_off
                            n_stride, K);
     else
         hipLaunchKernelGGL(pack_weight_kernel<PF32>, grid, dim3(256), 0, stream, W, (float*)out, N, K, n_off, n_stride, K);
+    return hipGetLastError();
+}
+
+hipError_t fold_layernorm_launch(const void* W, void* Wf, const float* gamma, const float* beta, float* c1, float* c2,
+                                 int N, int K, int dtype, hipStream_t stream) {
+    if (dtype == PTTS_BF16)
+        hipLaunchKernelGGL(fold_ln_kernel<PBF16>, dim3(N / 16), dim3(64), 0, stream, (const uint16_t*)W, (uint16_t*)Wf, gamma,
+                           beta, c1, c2, K);
+    else
+        hipLaunchKernelGGL(fold_ln_kernel<PF32>, dim3(N / 16), dim3(64), 0, stream, (const float*)W, (float*)Wf, gamma, beta,
+                           c1, c2, K);
     return hipGetLastError();
 }
 

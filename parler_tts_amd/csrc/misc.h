@@ -13,6 +13,7 @@ struct EmbedArgs {
     int P = 0;
     const StepState* state = nullptr;
     float* x = nullptr;                  // [B][D] residual stream
+    void* xfrag = nullptr;               // optional fragment-layout copy of x (weight dtype) for the folded LayerNorm path
 };
 
 struct SelectArgs {

@@ -50,7 +50,13 @@ __global__ __launch_bounds__(256) void embed_codebooks_kernel(EmbedArgs a) {
             Vec4<P>::load(tab + ((size_t)k * a.rows + toks[k]) * a.D + d, t);
             s[0] = s[0] + t[0]; s[1] = s[1] + t[1]; s[2] = s[2] + t[2]; s[3] = s[3] + t[3];
         }
-        *reinterpret_cast<float4*>(a.x + (size_t)b * a.D + d) = make_float4(s[0] + pe[0], s[1] + pe[1], s[2] + pe[2], s[3] + pe[3]);
+        const float o[4] = {s[0] + pe[0], s[1] + pe[1], s[2] + pe[2], s[3] + pe[3]};
+        *reinterpret_cast<float4*>(a.x + (size_t)b * a.D + d) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.xfrag) {
+            elem_t* xf = reinterpret_cast<elem_t*>(a.xfrag) + (size_t)(b >> 5) * 32 * a.D;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xf[frag_off<P>(b & 31, d + r)] = to_elem<P>(o[r]);
+        }
     }
 }
 
@@ -63,8 +69,12 @@ __global__ void embed_prompt_kernel(EmbedArgs a) {
     const long long tok = a.prompt_ids[(size_t)b * a.P + pos];
     const elem_t* row = reinterpret_cast<const elem_t*>(a.prompt_table) + (size_t)tok * a.D;
     const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)pos * a.D;
-    for (int d = threadIdx.x; d < a.D; d += blockDim.x)
-        a.x[(size_t)b * a.D + d] = from_elem<P>(row[d]) + from_elem<P>(ptab[d]);
+    elem_t* xf = a.xfrag ? reinterpret_cast<elem_t*>(a.xfrag) + (size_t)(b >> 5) * 32 * a.D : nullptr;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+        const float v = from_elem<P>(row[d]) + from_elem<P>(ptab[d]);
+        a.x[(size_t)b * a.D + d] = v;
+        if (xf) xf[frag_off<P>(b & 31, d)] = to_elem<P>(v);
+    }
 }
 
 __global__ void advance_prompt_kernel(StepState* s) { s->pos += 1; }
