@@ -11,7 +11,10 @@
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in _host
  *   - tensors are caller-owned; the engine owns only its packed weights, the paged KV pools and
  *     workspaces (allocated in ptts_create / ptts_prepare, never in the per-step calls)
- *   - every call that launches work is asynchronous on `stream` (a hipStream_t passed as void*)
+ *   - every call that launches work is asynchronous on `stream` (a hipStream_t passed as void*).
+ *     NULL (the legacy default stream, which cannot be captured into a hipGraph) is accepted too: the
+ *     work then runs on a stream the engine owns and the call is host-synchronous (it waits for the
+ *     NULL stream before starting and returns when its own work has finished)
  *   - return value: 0 = ok, negative = PTTS_E_* ; ptts_last_error() gives the text (HIP error
  *     strings included); no exceptions cross the ABI
  *   - one engine per device; not thread-safe per engine, re-entrant across engines
