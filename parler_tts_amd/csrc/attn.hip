@@ -15,6 +15,7 @@
 // hipGraph serves every step.
 #include "ptts_common.h"
 #include "attn.h"
+#include <cstdlib>
 
 namespace {
 
@@ -204,6 +205,120 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Single-page variant (S <= 64 keys known on the host: cross-attention over a short description).
+// One WAVE per (utterance, head), four waves per workgroup, no LDS and no barrier: every K and V tile
+// of the page is requested up front (S/TPW loads each), the softmax runs on DPP/shuffle reductions
+// across the token-lanes, and the 64 outputs leave as eight 16-byte fragment stores.  The general
+// kernel above spends ~6.7 us on a 40-key context (8 waves, 8 barriers); this one has a single
+// dependent global access (page id -> tiles).
+// ------------------------------------------------------------------------------------------------
+template <typename P, typename OP>
+__global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
+    typedef typename P::elem_t elem_t;
+    typedef KVLoad<P> L;
+    typedef typename L::raw_t raw_t;
+    constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT, NT = 64 / TPW;   // NT tiles cover one page
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (h >= H) return;
+    const int S = a.len;
+    const int tt = lane / LPT, c = lane % LPT;
+    const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
+    const int page = a.pool.block_table[b * a.pool.max_blocks];
+    const elem_t* kp = pool + (size_t)page * a.pool.page_elems() +
+                       (size_t)(a.layer * 2 * a.pool.H + h) * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM + c * EPL;
+    const size_t v_off = (size_t)a.pool.H * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM;
+    // every tile of the page is requested unconditionally (token index clamped to S-1): straight-line code, so all
+    // 2*NT loads are in flight together; tiles past S are masked out of the arithmetic instead
+    raw_t kb[NT], vb[NT];
+    float bs[NT];
+    const bool has_bias = a.bias != nullptr;
+    const float* brow = has_bias ? a.bias + (size_t)b * a.ld_bias : a.q;   // a.q: any readable floats, result unused
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        int tok = u * TPW + tt;
+        tok = tok < S ? tok : S - 1;
+        kb[u] = *reinterpret_cast<const raw_t*>(kp + (size_t)tok * PTTS_HEAD_DIM);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        int tok = u * TPW + tt;
+        tok = tok < S ? tok : S - 1;
+        vb[u] = *reinterpret_cast<const raw_t*>(kp + v_off + (size_t)tok * PTTS_HEAD_DIM);
+    }
+    float q[EPL];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL);
+#pragma unroll
+        for (int j = 0; j < EPL / 4; ++j) {
+            const f32x4 v = qp[j];
+            q[4 * j] = v[0]; q[4 * j + 1] = v[1]; q[4 * j + 2] = v[2]; q[4 * j + 3] = v[3];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        int tok = u * TPW + tt;
+        tok = tok < S ? tok : S - 1;
+        const float bv = brow[tok];
+        bs[u] = has_bias ? bv : 0.f;
+    }
+    // hipcc otherwise sinks the V loads below the score arithmetic; an empty asm use pins every load above this point
+#pragma unroll
+    for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(kb[u]));
+#pragma unroll
+    for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(vb[u]));
+    // scores: every lane of a token row ends up with the row's full dot product
+    float sc[NT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        float kf[EPL];
+        L::unpack(kb[u], kf);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) d = fmaf(q[j], kf[j], d);
+        d = (LPT == 8) ? sum_oct(d) : sum_row16(d);
+        sc[u] = (u * TPW + tt < S) ? d + bs[u] : -INFINITY;
+        m = fmaxf(m, sc[u]);
+    }
+    // across the token-lanes (lanes with equal c): xor 8 (bf16 only), 16, 32
+    if (LPT == 8) m = fmaxf(m, dpp_f<0x128>(m));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        sc[u] = (u * TPW + tt < S) ? expf(sc[u] - m) : 0.f;
+        sum += sc[u];
+    }
+    if (LPT == 8) sum += dpp_f<0x128>(sum);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    float acc[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const float p = sc[u] / sum;
+        float vf[EPL];
+        L::unpack(vb[u], vf);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        if (LPT == 8) acc[j] += dpp_f<0x128>(acc[j]);
+        acc[j] += __shfl_xor(acc[j], 16);
+        acc[j] += __shfl_xor(acc[j], 32);
+    }
+    if (tt == 0) {
+        typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(b >> 5) * 32 * a.D;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) of[frag_off<OP>(b & 31, h * PTTS_HEAD_DIM + c * EPL + j)] = to_elem<OP>(acc[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Full (bidirectional) attention for the T5 encoder: T <= 512 tokens, one workgroup per (head, b).
 // scores = q.k (no scaling) + rel-pos bias[h][bucket(j - i)] + (1 - mask_j) * finfo.min; softmax fp32.
 // (HF:models/t5/modeling_t5.py:144-173, 217-280.)  q/k/v row-major fp32 [B*T][3*inner] as written by
@@ -272,6 +387,18 @@ hipError_t attn_init() {
 }
 
 hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream) {
+    static const bool page_kernel = getenv("PTTS_ATTN_NO_PAGE_KERNEL") == nullptr;   // A/B switch
+    if (page_kernel && !a.len_from_state && a.len <= PTTS_PAGE_TOKENS) {
+        dim3 pgrid((H + 3) / 4, B), pblock(256);
+        if (cache_dtype == PTTS_BF16) {
+            if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_page_kernel<PBF16, PBF16>), pgrid, pblock, 0, stream, a, H);
+            else hipLaunchKernelGGL((attn_page_kernel<PBF16, PF32>), pgrid, pblock, 0, stream, a, H);
+        } else {
+            if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_page_kernel<PF32, PBF16>), pgrid, pblock, 0, stream, a, H);
+            else hipLaunchKernelGGL((attn_page_kernel<PF32, PF32>), pgrid, pblock, 0, stream, a, H);
+        }
+        return hipGetLastError();
+    }
     size_t lds = ((size_t)a.s_cap + NWAVES * 64 + NWAVES + a.pool.max_blocks) * sizeof(float);
     dim3 grid(H, B), block(NWAVES * 64);
 #define PTTS_ATTN_LAUNCH(P_, O_)                                                                             \
