@@ -187,6 +187,7 @@ KVPool make_pool(const ptts_engine* e, bool cross) {
     p.max_blocks = cross ? e->cross_blocks : e->self_blocks;
     p.H = e->cfg.heads;
     p.L = e->cfg.layers;
+    p.n_pages = cross ? e->cfg.max_batch * e->cross_blocks : e->self_pages;
     return p;
 }
 

@@ -78,18 +78,22 @@ template <> __host__ __device__ inline size_t wpack_off<PF32>(int n, int k, int 
 }
 
 // ---- paged KV pool -------------------------------------------------------------------------------------
-// page p holds 64 tokens of ONE utterance for all layers/heads: [L][2 (K,V)][H][64 tok][64 dim]
+// One pool = [L][2 (K,V)][n_pages][H][64 tok][64 dim]: a page id names 64 tokens of ONE utterance in every
+// (layer, K/V) slab.  Slabs are per layer so that one attention launch (one layer) reads a dense region of
+// n_pages * H * 8 KiB per K or V instead of 8 KiB chunks strided by a whole multi-layer page.
 struct KVPool {
     void* base;            // element type = cache dtype
     const int* block_table;  // [B][max_blocks] page ids
     int max_blocks;
     int H;
     int L;
-    __host__ __device__ size_t page_elems() const { return (size_t)L * 2 * H * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM; }
+    int n_pages;           // pages in the pool (slab stride)
+    __host__ __device__ size_t slab_elems() const { return (size_t)H * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM; }   // one page of one (layer, kv)
+    __host__ __device__ size_t kv_elems() const { return (size_t)n_pages * slab_elems(); }                     // one (layer, kv) slab
     __device__ size_t elem_off(int b, int layer, int kv, int h, int tok) const {
         int page = block_table[b * max_blocks + (tok >> 6)];
-        return (size_t)page * page_elems() +
-               ((size_t)((layer * 2 + kv) * H + h) * PTTS_PAGE_TOKENS + (tok & 63)) * PTTS_HEAD_DIM;
+        return ((size_t)(layer * 2 + kv) * n_pages + page) * slab_elems() +
+               ((size_t)h * PTTS_PAGE_TOKENS + (tok & 63)) * PTTS_HEAD_DIM;
     }
 };
 
