@@ -77,8 +77,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     // page ids once into LDS: KV addresses then depend on no global load
     for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[b * a.pool.max_blocks + i];
     __syncthreads();
-    const size_t page_elems = a.pool.slab_elems();       // stride between two pages inside the layer's K (or V) slab
-    const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM + c * EPL;
+    const size_t page_elems = a.pool.page_elems();       // stride between two pages inside this head's K (or V) slab
+    const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
     const int ntiles = (S + TPW - 1) / TPW;
 
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     const int tt = lane / LPT, c = lane % LPT;
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
     const int page = a.pool.block_table[b * a.pool.max_blocks];
-    const elem_t* kp = pool + (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)page * a.pool.slab_elems() +
-                       (size_t)h * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM + c * EPL;
+    const elem_t* kp = pool + (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() +
+                       (size_t)page * a.pool.page_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
     // every tile of the page is requested unconditionally (token index clamped to S-1): straight-line code, so all
     // 2*NT loads are in flight together; tiles past S are masked out of the arithmetic instead

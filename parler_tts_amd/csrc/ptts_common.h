@@ -78,22 +78,23 @@ template <> __host__ __device__ inline size_t wpack_off<PF32>(int n, int k, int 
 }
 
 // ---- paged KV pool -------------------------------------------------------------------------------------
-// One pool = [L][2 (K,V)][n_pages][H][64 tok][64 dim]: a page id names 64 tokens of ONE utterance in every
-// (layer, K/V) slab.  Slabs are per layer so that one attention launch (one layer) reads a dense region of
-// n_pages * H * 8 KiB per K or V instead of 8 KiB chunks strided by a whole multi-layer page.
+// One pool = [L][2 (K,V)][H][n_pages][64 tok][64 dim]: a page id names 64 tokens of ONE utterance in every
+// (layer, K/V, head) slab.  One attention launch (one layer) then reads a dense region, and a workgroup
+// (one utterance, one head) whose page ids are consecutive streams ONE contiguous run of 8 KiB pages
+// (measured: [page][L][2][H] 37.2 us per launch, [L][2][page][H] 34.0 us, this layout see DESIGN.md).
 struct KVPool {
     void* base;            // element type = cache dtype
     const int* block_table;  // [B][max_blocks] page ids
     int max_blocks;
     int H;
     int L;
-    int n_pages;           // pages in the pool (slab stride)
-    __host__ __device__ size_t slab_elems() const { return (size_t)H * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM; }   // one page of one (layer, kv)
-    __host__ __device__ size_t kv_elems() const { return (size_t)n_pages * slab_elems(); }                     // one (layer, kv) slab
+    int n_pages;           // pages in the pool
+    __host__ __device__ size_t page_elems() const { return (size_t)PTTS_PAGE_TOKENS * PTTS_HEAD_DIM; }   // one page of one (layer, kv, head)
+    __host__ __device__ size_t head_elems() const { return (size_t)n_pages * page_elems(); }             // one (layer, kv, head) slab
+    __host__ __device__ size_t kv_elems() const { return (size_t)H * head_elems(); }                     // one (layer, kv) slab
     __device__ size_t elem_off(int b, int layer, int kv, int h, int tok) const {
         int page = block_table[b * max_blocks + (tok >> 6)];
-        return ((size_t)(layer * 2 + kv) * n_pages + page) * slab_elems() +
-               ((size_t)h * PTTS_PAGE_TOKENS + (tok & 63)) * PTTS_HEAD_DIM;
+        return ((size_t)((layer * 2 + kv) * H + h) * n_pages + page) * page_elems() + (size_t)(tok & 63) * PTTS_HEAD_DIM;
     }
 };
 

@@ -74,11 +74,12 @@ for l in range(cfg.decoder.num_hidden_layers):
     q = F.linear(h, sd[p + "self_attn.q_proj.weight"]) * scale
     k = F.linear(h, sd[p + "self_attn.k_proj.weight"]); v = F.linear(h, sd[p + "self_attn.v_proj.weight"])
     run(base + 1); cmp(f"L{l} q", buf("q", (32, D))[:B], q)
-    # self pool: [L][2][n_pages][H][64][64]; utterance b starts at page b*max_blocks
+    # self pool: [L][2][H][n_pages][64][64]; utterance b starts at page b*max_blocks
     n_pages, max_blocks, page_bytes = eng.pool_info()
     pe = page_bytes // (4 if dtype == "fp32" else 2)
-    pool = buf("self_pool", (cfg.decoder.num_hidden_layers, 2, n_pages, H, 64, 64), fdt).float()
-    kk = pool[l, 0, torch.arange(B) * max_blocks, :, 0, :].reshape(B, D); vv = pool[l, 1, torch.arange(B) * max_blocks, :, 0, :].reshape(B, D)
+    pool = buf("self_pool", (cfg.decoder.num_hidden_layers, 2, H, n_pages, 64, 64), fdt).float()
+    kk = pool[l, 0, :, torch.arange(B) * max_blocks, 0, :].transpose(0, 1).reshape(B, D)
+    vv = pool[l, 1, :, torch.arange(B) * max_blocks, 0, :].transpose(0, 1).reshape(B, D)
     cmp(f"L{l} k cache", kk, k); cmp(f"L{l} v cache", vv, v)
     o = v  # one key
     run(base + 2); cmp(f"L{l} self-attn o", defrag(buf("attn_frag", (32 * D,), fdt).float(), 32, D)[:B], o)
@@ -89,8 +90,8 @@ for l in range(cfg.decoder.num_hidden_layers):
     run(base + 4); cmp(f"L{l} cross q", buf("q", (32, D))[:B], q)
     ck = F.linear(enc_h, sd[p + "encoder_attn.k_proj.weight"]).view(B, T, H, 64).transpose(1, 2)
     cv = F.linear(enc_h, sd[p + "encoder_attn.v_proj.weight"]).view(B, T, H, 64).transpose(1, 2)
-    cpool = buf("cross_pool", (cfg.decoder.num_hidden_layers, 2, 32, H, 64, 64), fdt).float()   # max_batch 32, one page each
-    cmp(f"L{l} cross K cache", cpool[l, 0, :B, :, :T, :], ck); cmp(f"L{l} cross V cache", cpool[l, 1, :B, :, :T, :], cv)
+    cpool = buf("cross_pool", (cfg.decoder.num_hidden_layers, 2, H, 32, 64, 64), fdt).float()   # max_batch 32, one page each
+    cmp(f"L{l} cross K cache", cpool[l, 0, :, :B, :T, :].transpose(0, 1), ck); cmp(f"L{l} cross V cache", cpool[l, 1, :, :B, :T, :].transpose(0, 1), cv)
     qh = q.view(B, 1, H, 64).transpose(1, 2)
     w = torch.softmax(qh @ ck.transpose(2, 3), dim=-1)
     o = (w @ cv).transpose(1, 2).reshape(B, D)
