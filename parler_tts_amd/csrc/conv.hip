@@ -187,40 +187,82 @@ __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
     const float* inb = a.in + (size_t)b * a.Tin * a.Cin;
     const _Float16* gwh = reinterpret_cast<const _Float16*>(a.w_hi);
     const _Float16* gwl = reinterpret_cast<const _Float16*>(a.w_lo);
-    for (int c0 = 0; c0 < a.Cin; c0 += KC3) {
-        // ---- stage the input window: Snake once per element, then the fp16 hi/lo split ----
-        for (int i = tid; i < win * (KC3 / 4); i += 512) {
-            const int r = i / (KC3 / 4), q = i % (KC3 / 4);
-            const int t = u0 + lo_r + r;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (t >= 0 && t < a.Tin) {
-                v = *reinterpret_cast<const float4*>(inb + (size_t)t * a.Cin + c0 + 4 * q);
-                if (a.alpha) {
-                    const float4 al = *reinterpret_cast<const float4*>(a.alpha + c0 + 4 * q);
-                    v.x = snake_f(v.x, al.x, 1.0f / (al.x + 1e-9f));
-                    v.y = snake_f(v.y, al.y, 1.0f / (al.y + 1e-9f));
-                    v.z = snake_f(v.z, al.z, 1.0f / (al.z + 1e-9f));
-                    v.w = snake_f(v.w, al.w, 1.0f / (al.w + 1e-9f));
+
+    // Software pipeline over the 32-channel chunks: the NEXT chunk's input window and tap weights are fetched
+    // into registers before this chunk's MFMA loop and written to LDS (Snake + fp16 split on the way) after it,
+    // so global/L2 latency hides under the matrix work instead of sitting between two barriers (the kernel
+    // holds one workgroup per CU: nothing else would cover it).  Measured on the 384-channel 7-tap layers:
+    // MFMA time was ~1/3 of the single-buffered kernel.
+    constexpr int XA = 6;                                             // window float4 per thread (win <= 384)
+    constexpr int WR = (MAX_TAPS * TN * (KC3 / 8) + 511) / 512;       // weight uint4 pairs per thread
+    const int nx = win * (KC3 / 4), nw = a.taps * TN * (KC3 / 8);
+    float4 xr[XA];
+    uint4 wrh[WR], wrl[WR];
+    float4 alr = make_float4(0, 0, 0, 0);
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < XA; ++k) {
+            const int i = tid + 512 * k;
+            xr[k] = make_float4(0, 0, 0, 0);
+            if (i < nx) {
+                const int r = i / (KC3 / 4), q = i % (KC3 / 4);
+                const int t = u0 + lo_r + r;
+                if (t >= 0 && t < a.Tin) xr[k] = *reinterpret_cast<const float4*>(inb + (size_t)t * a.Cin + c0 + 4 * q);
+            }
+        }
+        if (a.alpha) alr = *reinterpret_cast<const float4*>(a.alpha + c0 + 4 * (tid % (KC3 / 4)));   // q is the same for every k
+#pragma unroll
+        for (int k = 0; k < WR; ++k) {
+            const int i = tid + 512 * k;
+            wrh[k] = make_uint4(0, 0, 0, 0);
+            wrl[k] = make_uint4(0, 0, 0, 0);
+            if (i < nw) {
+                const int q = i % (KC3 / 8), n = (i / (KC3 / 8)) % TN, tap = i / ((KC3 / 8) * TN);
+                if (n0 + n < a.N) {
+                    const size_t g = ((size_t)tap * a.N + n0 + n) * a.Cin + c0 + 8 * q;
+                    wrh[k] = *reinterpret_cast<const uint4*>(gwh + g);
+                    wrl[k] = *reinterpret_cast<const uint4*>(gwl + g);
                 }
             }
-            _Float16 h[4], l[4];
-            split_h(v.x, h[0], l[0]); split_h(v.y, h[1], l[1]); split_h(v.z, h[2], l[2]); split_h(v.w, h[3], l[3]);
-            *reinterpret_cast<uint2*>(xh + (size_t)r * LDH + 4 * q) = *reinterpret_cast<uint2*>(h);
-            *reinterpret_cast<uint2*>(xl + (size_t)r * LDH + 4 * q) = *reinterpret_cast<uint2*>(l);
         }
-        // ---- stage the pre-split weights of every tap for this chunk (16-byte copies) ----
-        for (int i = tid; i < a.taps * TN * (KC3 / 8); i += 512) {
-            const int q = i % (KC3 / 8), n = (i / (KC3 / 8)) % TN, tap = i / ((KC3 / 8) * TN);
-            uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-            if (n0 + n < a.N) {
-                const size_t g = ((size_t)tap * a.N + n0 + n) * a.Cin + c0 + 8 * q;
-                vh = *reinterpret_cast<const uint4*>(gwh + g);
-                vl = *reinterpret_cast<const uint4*>(gwl + g);
+    };
+    auto stash = [&]() {
+        const bool snake = a.alpha != nullptr;
+        const float4 inv = make_float4(1.0f / (alr.x + 1e-9f), 1.0f / (alr.y + 1e-9f), 1.0f / (alr.z + 1e-9f), 1.0f / (alr.w + 1e-9f));
+#pragma unroll
+        for (int k = 0; k < XA; ++k) {
+            const int i = tid + 512 * k;
+            if (i < nx) {
+                const int r = i / (KC3 / 4), q = i % (KC3 / 4);
+                float4 v = xr[k];
+                if (snake) {   // Snake(0) = 0, so the zero padding needs no special case
+                    v.x = snake_f(v.x, alr.x, inv.x); v.y = snake_f(v.y, alr.y, inv.y);
+                    v.z = snake_f(v.z, alr.z, inv.z); v.w = snake_f(v.w, alr.w, inv.w);
+                }
+                _Float16 h[4], l[4];
+                split_h(v.x, h[0], l[0]); split_h(v.y, h[1], l[1]); split_h(v.z, h[2], l[2]); split_h(v.w, h[3], l[3]);
+                *reinterpret_cast<uint2*>(xh + (size_t)r * LDH + 4 * q) = *reinterpret_cast<uint2*>(h);
+                *reinterpret_cast<uint2*>(xl + (size_t)r * LDH + 4 * q) = *reinterpret_cast<uint2*>(l);
             }
-            *reinterpret_cast<uint4*>(wh + ((size_t)tap * TN + n) * LDH + 8 * q) = vh;
-            *reinterpret_cast<uint4*>(wl + ((size_t)tap * TN + n) * LDH + 8 * q) = vl;
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WR; ++k) {
+            const int i = tid + 512 * k;
+            if (i < nw) {
+                const int q = i % (KC3 / 8), n = (i / (KC3 / 8)) % TN, tap = i / ((KC3 / 8) * TN);
+                *reinterpret_cast<uint4*>(wh + ((size_t)tap * TN + n) * LDH + 8 * q) = wrh[k];
+                *reinterpret_cast<uint4*>(wl + ((size_t)tap * TN + n) * LDH + 8 * q) = wrl[k];
+            }
+        }
+    };
+
+    fetch(0);
+    stash();
+    for (int c0 = 0; c0 < a.Cin; c0 += KC3) {
+        __syncthreads();                                  // chunk c0 is in LDS
+        const bool more = c0 + KC3 < a.Cin;
+        if (more) fetch(c0 + KC3);
+        asm volatile("" ::: "memory");                    // keep the fetch above the MFMA loop (hipcc sinks loads to their use)
         for (int tap = 0; tap < a.taps; ++tap) {
             const int roff = tap * a.tstep + a.toff - lo_r;
             const size_t xo = (size_t)(w * 32 + roff + (lane & 15)) * LDH + 8 * (lane >> 4);
@@ -242,7 +284,8 @@ __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
                 acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x1h, acc[1][j], 0, 0, 0);
             }
         }
-        __syncthreads();
+        __syncthreads();                                  // every wave is done reading chunk c0
+        if (more) stash();
     }
 
     // ---- epilogue (same as the fp32 kernel) ----
@@ -359,7 +402,8 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
         int TN = (a.N % 96 == 0 && conv_h3_lds(a, 96) <= 160 * 1024) ? 96 : 64;
         if (a.N % 64 != 0 && a.N % 96 != 0) TN = a.N <= 64 ? 64 : 96;
         const size_t lds3 = conv_h3_lds(a, TN);
-        if (lds3 <= 160 * 1024) {
+        const int span = (a.taps - 1) * (a.tstep >= 0 ? a.tstep : -a.tstep);
+        if (lds3 <= 160 * 1024 && TM3 + span <= 384) {     // 384 = window rows the register staging covers
             dim3 grid((a.N + TN - 1) / TN, (a.U + TM3 - 1) / TM3, a.B);
             if (TN == 64) hipLaunchKernelGGL(conv_kernel_h3<64>, grid, dim3(512), lds3, s, a);
             else hipLaunchKernelGGL(conv_kernel_h3<96>, grid, dim3(512), lds3, s, a);
