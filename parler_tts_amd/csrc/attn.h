@@ -16,6 +16,7 @@ struct AttnArgs {
     int s_cap = 0;                // LDS score capacity (>= max keys, multiple of 4)
     void* ofrag = nullptr;        // output in B-fragment order, feature count D
     int D = 0;
+    int no_page_kernel = 0;       // 1: always use the general kernel (A/B and equivalence tests)
 };
 
 struct FullAttnArgs {

@@ -387,8 +387,7 @@ hipError_t attn_init() {
 }
 
 hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream) {
-    static const bool page_kernel = getenv("PTTS_ATTN_NO_PAGE_KERNEL") == nullptr;   // A/B switch
-    if (page_kernel && !a.len_from_state && a.len <= PTTS_PAGE_TOKENS) {
+    if (!a.no_page_kernel && !a.len_from_state && a.len <= PTTS_PAGE_TOKENS) {
         dim3 pgrid((H + 3) / 4, B), pblock(256);
         if (cache_dtype == PTTS_BF16) {
             if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_page_kernel<PBF16, PBF16>), pgrid, pblock, 0, stream, a, H);

@@ -97,6 +97,7 @@ struct ptts_engine {
     Folded heads_f;
     bool fold_ln = false;      // LayerNorm applied after the MFMA on gamma-folded weights (default for bf16)
     bool fold_dirty = true;    // a tensor arrived since the folded copies were built
+    bool no_page_kernel = false;   // PTTS_ATTN_NO_PAGE_KERNEL=1: cross-attention on the general kernel (A/B, tests)
     float *lnf_g = nullptr, *lnf_b = nullptr, *enc_proj_bias = nullptr;
     void *embed_tokens = nullptr, *pos_table = nullptr, *embed_prompts = nullptr;
     // T5
@@ -324,6 +325,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         a.q = e->q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
         a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS;
         a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = e->attn_frag; a.D = D;
+        a.no_page_kernel = e->no_page_kernel ? 1 : 0;
         DBG_GATE(e);
         HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
         g = GemmArgs();
@@ -553,6 +555,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->no_graph = getenv("PTTS_NO_GRAPH") != nullptr;
     e->fold_ln = cfg->dtype == PTTS_DTYPE_BF16;
     if (const char* v = getenv("PTTS_LN_FOLD")) e->fold_ln = atoi(v) != 0;
+    e->no_page_kernel = getenv("PTTS_ATTN_NO_PAGE_KERNEL") != nullptr;
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     if (cfg->dac_hidden > 0) {
         if (cfg->dac_n_up <= 0 || cfg->dac_n_up > 8 || cfg->dac_hidden % (16 << cfg->dac_n_up) != 0 || cfg->dac_latent % 16 != 0) {
@@ -1111,11 +1114,28 @@ int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* 
     g.W = wp; g.N = Np; g.K = K; g.M = M; g.pro = prologue; g.x = X; g.ldx = K; g.gamma = gamma; g.beta = beta; g.eps = eps;
     g.epi = EPI_ROWMAJOR; g.out = Y; g.ldo = N; g.bias = bias; g.act = act;
     if (N % 16 != 0) { (void)hipFree(wp); return fail(PTTS_E_INVALID, "test gemm needs N %% 16 == 0"); }
+    void *wf = nullptr, *xf = nullptr;
+    float *c1 = nullptr, *c2 = nullptr;
+    if (prologue == 4) {   // LayerNorm through the folded path: gamma into the weights, raw rows as fragments
+        const size_t mrows = (size_t)(M + 31) / 32 * 32;
+        HIP_TRY(hipMalloc(&wf, (size_t)Np * K * esz));
+        HIP_TRY(hipMalloc((void**)&c1, Np * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&c2, Np * sizeof(float)));
+        HIP_TRY(hipMalloc(&xf, mrows * K * esz));
+        HIP_TRY(hipMemsetAsync(xf, 0, mrows * K * esz, s));
+        HIP_TRY(fold_layernorm_launch(wp, wf, gamma, beta, c1, c2, Np, K, dtype, s));
+        HIP_TRY(rows_to_frag_launch(X, xf, M, K, dtype, s));
+        g.W = wf; g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = xf; g.fold = 1; g.c1 = c1; g.c2 = c2;
+    }
     int v = gemm_validate(g, dtype);
     hipError_t he = hipSuccess;
     if (v == 0) he = gemm_launch(g, dtype, s);
     hipError_t se = hipStreamSynchronize(s);
     (void)hipFree(wp);
+    if (wf) (void)hipFree(wf);
+    if (xf) (void)hipFree(xf);
+    if (c1) (void)hipFree(c1);
+    if (c2) (void)hipFree(c2);
     if (v != 0) return fail(PTTS_E_INVALID, "gemm shape rejected (code %d)", v);
     if (he != hipSuccess) return fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(he));
     if (se != hipSuccess) return fail(PTTS_E_HIP, "gemm execution failed: %s", hipGetErrorString(se));

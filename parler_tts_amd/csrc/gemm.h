@@ -50,4 +50,6 @@ hipError_t pack_weight_launch(const float* W, void* out, int N, int K, int n_off
 // c2[n] = sum_k beta[k] * W[n][k]; N is the padded row count of the packed matrix
 hipError_t fold_layernorm_launch(const void* W, void* Wf, const float* gamma, const float* beta, float* c1, float* c2,
                                  int N, int K, int dtype, hipStream_t stream);
+// row-major fp32 [M][K] -> fragment layout of the weight dtype (test hook for the folded path)
+hipError_t rows_to_frag_launch(const float* X, void* xfrag, int M, int K, int dtype, hipStream_t stream);
 hipError_t convert_launch(const float* src, void* dst, size_t n, int dtype, hipStream_t stream);

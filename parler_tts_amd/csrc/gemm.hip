@@ -533,6 +533,14 @@ __global__ __launch_bounds__(64) void fold_ln_kernel(const typename P::elem_t* _
 }
 
 template <typename P>
+__global__ void rows_to_frag_kernel(const float* __restrict__ X, typename P::elem_t* xf, int M, int K) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * K) return;
+    const int r = (int)(idx / K), k = (int)(idx % K);
+    xf[(size_t)(r >> 5) * 32 * K + frag_off<P>(r & 31, k)] = to_elem<P>(X[idx]);
+}
+
+template <typename P>
 __global__ void convert_kernel(const float* __restrict__ src, typename P::elem_t* dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = to_elem<P>(src[i]);
@@ -590,6 +598,13 @@ hipError_t fold_layernorm_launch(const void* W, void* Wf, const float* gamma, co
     else
         hipLaunchKernelGGL(fold_ln_kernel<PF32>, dim3(N / 16), dim3(64), 0, stream, (const float*)W, (float*)Wf, gamma, beta,
                            c1, c2, K);
+    return hipGetLastError();
+}
+
+hipError_t rows_to_frag_launch(const float* X, void* xfrag, int M, int K, int dtype, hipStream_t stream) {
+    dim3 grid((unsigned)(((size_t)M * K + 255) / 256));
+    if (dtype == PTTS_BF16) hipLaunchKernelGGL(rows_to_frag_kernel<PBF16>, grid, dim3(256), 0, stream, X, (uint16_t*)xfrag, M, K);
+    else hipLaunchKernelGGL(rows_to_frag_kernel<PF32>, grid, dim3(256), 0, stream, X, (float*)xfrag, M, K);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@ Tolerances
               teacher-forced argmax agreement >= 90 % of the kept positions
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -84,6 +85,36 @@ def test_gemm_against_torch(hip, dtype, M, N, K, pro, act):
     err = (Y.double() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= (2e-5 if dtype == "fp32" else 2e-3) * max(scale, 1.0), (err, scale)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K,act,mean", [(32, 1024, 1024, 0, 0.0), (32, 3072, 1024, 0, 0.7), (17, 4096, 1024, 1, -1.5),
+                                            (40, 1024, 1024, 0, 0.3), (32, 9792, 1024, 0, 2.0), (32, 256, 2048, 0, 0.5)])
+def test_folded_layernorm_gemm_against_torch(hip, dtype, M, N, K, act, mean):
+    """LayerNorm applied AFTER the MFMA (gamma folded into the weights, statistics from ones.x / x.x^T MFMAs):
+    y = rstd * (x.W' - mean * c1) + c2 must equal LayerNorm(x) @ W^T.  Reference M:446/467/487/959 + M:256-259.
+    Rows carry a non-zero mean so the E[x^2] - mean^2 form and the mean * c1 cancellation are exercised."""
+    g = torch.Generator().manual_seed(M * 13 + N + K)
+    W = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    X = (mean + torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2)).cuda()
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).cuda()
+    beta = (0.1 * torch.randn(K, generator=g)).cuda()
+    bias = torch.zeros(N).cuda()
+    Y = torch.empty(M, N, device="cuda")
+    dt = 1 if dtype == "bf16" else 0
+    rc = hip.ptts_test_gemm(dt, M, N, K, W.data_ptr(), X.data_ptr(), 4, gamma.data_ptr(), beta.data_ptr(),
+                            C.c_float(1e-5), act, bias.data_ptr(), Y.data_ptr(), None)
+    assert rc == 0, hip.ptts_last_error()
+    Xd, Wd = X.double(), W.double()
+    if dtype == "bf16":   # the MFMA (and therefore the statistics) see the bf16-rounded rows and weights
+        Xd = X.bfloat16().double()
+        Wd = W.bfloat16().double()
+    ref = torch.nn.functional.layer_norm(Xd, (K,), gamma.double(), beta.double(), 1e-5) @ Wd.t()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    err = (Y.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= (5e-5 if dtype == "fp32" else 3e-3) * max(scale, 1.0), (err, scale)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -636,3 +667,43 @@ def test_decoder_without_enc_to_dec_proj(hip):
     sd = synthetic_state_dict(cfg, seed=13, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
     got, want, _, _ = _oracle_vs_engine(cfg, sd, "fp32", B=3, T=7, P=4, L=14, seed=6, steps=10)
     assert (got - want).abs().max() < 2e-4
+
+
+def _fresh_engine_logits(name, dtype, env):
+    """teacher-forced per-step logits from a NEW engine created under `env` (the switches are read in ptts_create)"""
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        _models.clear()
+        torch.cuda.empty_cache()
+        return run_engine_case(name, dtype, teacher_force=True)[3]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        _models.clear()
+
+
+def test_folded_and_staged_layernorm_agree(hip):
+    """same model, same teacher-forced tokens: LayerNorm folded behind the MFMA vs the staged two-pass prologue"""
+    a = _fresh_engine_logits("tiny_greedy", "fp32", {"PTTS_LN_FOLD": "1"})
+    b = _fresh_engine_logits("tiny_greedy", "fp32", {"PTTS_LN_FOLD": "0"})
+    assert (a - b).abs().max().item() < 1e-4
+    a = _fresh_engine_logits("tiny_greedy", "bf16", {"PTTS_LN_FOLD": "1"})
+    b = _fresh_engine_logits("tiny_greedy", "bf16", {"PTTS_LN_FOLD": "0"})
+    assert (a - b).abs().max().item() < 0.08
+    assert (a.argmax(-1) == b.argmax(-1)).float().mean().item() > 0.9
+
+
+def test_page_attention_kernel_equals_general_kernel(hip):
+    """cross-attention over a single page: one-wave kernel vs the general paged kernel (same arithmetic, other order)"""
+    for name in ("tiny_greedy_ragged", "tiny_cfg"):      # padded description keys / fully masked null rows
+        a = _fresh_engine_logits(name, "fp32", {"PTTS_ATTN_NO_PAGE_KERNEL": None})
+        b = _fresh_engine_logits(name, "fp32", {"PTTS_ATTN_NO_PAGE_KERNEL": "1"})
+        assert (a - b).abs().max().item() < 2e-5, name
