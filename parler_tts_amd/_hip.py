@@ -61,17 +61,19 @@ _lib: Optional[C.CDLL] = None
 
 
 def load_library() -> C.CDLL:
+    # PTTS_HIP_LIB: alternative build of the same ABI (A/B experiments)
     """dlopen the engine; raises HipLibraryMissing with build instructions when it is absent."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PTTS_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
         raise HipLibraryMissing(
-            f"{LIB_PATH} not found. The Parler-TTS hot path only exists as HIP code for gfx950; build it with "
+            f"{path} not found. The Parler-TTS hot path only exists as HIP code for gfx950; build it with "
             f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C parler_tts_amd/csrc`). "
             f"There is no CPU or PyTorch fallback."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
     lib.ptts_last_error.restype = C.c_char_p
     lib.ptts_abi_version.restype = i32

@@ -97,6 +97,7 @@ struct ptts_engine {
     Folded heads_f;
     bool fold_ln = false;      // LayerNorm applied after the MFMA on gamma-folded weights (default for bf16)
     bool fold_dirty = true;    // a tensor arrived since the folded copies were built
+    int fold_mask = 15;
     bool no_page_kernel = false;   // PTTS_ATTN_NO_PAGE_KERNEL=1: cross-attention on the general kernel (A/B, tests)
     float *lnf_g = nullptr, *lnf_b = nullptr, *enc_proj_bias = nullptr;
     void *embed_tokens = nullptr, *pos_table = nullptr, *embed_prompts = nullptr;
@@ -246,8 +247,9 @@ int load_table(ptts_engine* e, void** dst, size_t total, size_t off, size_t n, c
 #define DBG_GATE(e) do { if ((e)->dbg_stop >= 0 && (e)->dbg_count++ >= (e)->dbg_stop) return PTTS_OK; } while (0)
 
 // switch a LayerNorm-prologue projection to its folded form (fragment input = raw residual rows)
-void use_fold(const ptts_engine* e, GemmArgs* g, const Folded& f) {
+void use_fold(const ptts_engine* e, GemmArgs* g, const Folded& f, int which = 0) {
     if (!e->fold_ln) return;
+    if (!(e->fold_mask & (1 << which))) return;      // PTTS_FOLD_MASK: bit 0 QKV, 1 cross-q, 2 fc1, 3 LM heads (A/B)
     g->W = f.w; g->pro = PRO_FRAG; g->xfrag = e->x_frag; g->x = nullptr; g->fold = 1; g->c1 = f.c1; g->c2 = f.c2;
 }
 
@@ -286,7 +288,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         g = GemmArgs();
         g.W = w.qkv.ptr; g.N = 3 * D; g.K = D; g.M = M;
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.eps = 1e-5f;
-        use_fold(e, &g, w.qkv_f);
+        use_fold(e, &g, w.qkv_f, 0);
         g.epi = EPI_QKV_SELF; g.out = e->q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
         g.state = e->state; g.D = D;
         DBG_GATE(e);
@@ -316,7 +318,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         g = GemmArgs();
         g.W = w.cq.ptr; g.N = D; g.K = D; g.M = M;
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.eps = 1e-5f;
-        use_fold(e, &g, w.cq_f);
+        use_fold(e, &g, w.cq_f, 1);
         g.epi = EPI_Q_SCALE; g.out = e->q; g.ldo = D; g.scale = scale;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
@@ -337,7 +339,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         g = GemmArgs();
         g.W = w.fc1.ptr; g.N = F; g.K = D; g.M = M;
         g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.eps = 1e-5f;
-        use_fold(e, &g, w.fc1_f);
+        use_fold(e, &g, w.fc1_f, 2);
         g.epi = EPI_ACT_FRAG; g.act = ACT_GELU; g.ofrag = e->mlp_frag; g.ldo = F;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
@@ -375,7 +377,7 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
     GemmArgs g;
     g.W = e->heads.ptr; g.N = c.codebooks * e->Vp; g.K = c.hidden; g.M = e->B_eff;
     g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = c.hidden; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.eps = 1e-5f;
-    use_fold(e, &g, e->heads_f);
+    use_fold(e, &g, e->heads_f, 3);
     g.epi = EPI_ROWMAJOR; g.out = e->logits; g.ldo = c.codebooks * e->Vp;
     PTTS_TRY(launch_gemm(e, g, s));
     SelectArgs sa;
@@ -556,6 +558,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->fold_ln = cfg->dtype == PTTS_DTYPE_BF16;
     if (const char* v = getenv("PTTS_LN_FOLD")) e->fold_ln = atoi(v) != 0;
     e->no_page_kernel = getenv("PTTS_ATTN_NO_PAGE_KERNEL") != nullptr;
+    if (const char* v = getenv("PTTS_FOLD_MASK")) e->fold_mask = atoi(v);
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     if (cfg->dac_hidden > 0) {
         if (cfg->dac_n_up <= 0 || cfg->dac_n_up > 8 || cfg->dac_hidden % (16 << cfg->dac_n_up) != 0 || cfg->dac_latent % 16 != 0) {
@@ -1116,6 +1119,13 @@ int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* 
     if (N % 16 != 0) { (void)hipFree(wp); return fail(PTTS_E_INVALID, "test gemm needs N %% 16 == 0"); }
     void *wf = nullptr, *xf = nullptr;
     float *c1 = nullptr, *c2 = nullptr;
+    if (prologue == 5) {   // plain rows through the fragment-input path (no normalisation)
+        const size_t mrows = (size_t)(M + 31) / 32 * 32;
+        HIP_TRY(hipMalloc(&xf, mrows * K * esz));
+        HIP_TRY(hipMemsetAsync(xf, 0, mrows * K * esz, s));
+        HIP_TRY(rows_to_frag_launch(X, xf, M, K, dtype, s));
+        g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = xf;
+    }
     if (prologue == 4) {   // LayerNorm through the folded path: gamma into the weights, raw rows as fragments
         const size_t mrows = (size_t)(M + 31) / 32 * 32;
         HIP_TRY(hipMalloc(&wf, (size_t)Np * K * esz));

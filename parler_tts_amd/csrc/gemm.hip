@@ -21,6 +21,7 @@
 // T5 RMSNorm / gated-GELU HF:models/t5/modeling_t5.py:50-66,97-108.
 #include "ptts_common.h"
 #include "gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -50,9 +51,15 @@ template <> struct Tile<PBF16> {
     static __device__ inline wfrag load_lds(const uint16_t* xs, int ld, int r, int ks_local, int lane) {
         return *reinterpret_cast<const bf16x8*>(xs + (size_t)r * ld + ks_local * 32 + 8 * (lane >> 4));
     }
-    static __device__ inline wfrag ones() {
-        const __bf16 o = (__bf16)1.0f;
-        return wfrag{o, o, o, o, o, o, o, o};
+    // per-lane sum and sum of squares of the 8 values of a fragment (fp32)
+    static __device__ inline void stats(const wfrag& b, float& sum, float& sq) {
+        const u32x4 r = __builtin_bit_cast(u32x4, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lo = __builtin_bit_cast(float, r[i] << 16), hi = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+            sum += lo; sum += hi;
+            sq = fmaf(lo, lo, sq); sq = fmaf(hi, hi, sq);
+        }
     }
 };
 template <> struct Tile<PF32> {
@@ -69,7 +76,10 @@ template <> struct Tile<PF32> {
         v[0] = p[0]; v[1] = p[4]; v[2] = p[8]; v[3] = p[12];
         return v;
     }
-    static __device__ inline wfrag ones() { return wfrag{1.f, 1.f, 1.f, 1.f}; }
+    static __device__ inline void stats(const wfrag& b, float& sum, float& sq) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float v = b[i]; sum += v; sq = fmaf(v, v, sq); }
+    }
 };
 
 template <typename P>
@@ -148,8 +158,11 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
 template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // FOLD (fragment input, NB = 1): the fragments are the raw residual rows and W carries the LayerNorm gain.
-    // Row statistics come from the matrix cores: ones . x gives sum(x) in every accumulator row, x . x^T has
-    // sum(x^2) on its diagonal (A and B operands of the 16x16 MFMA share one register layout).
+    // Row statistics (sum x, sum x^2 over the bf16/fp32 values the MFMA consumes) are accumulated per lane on the
+    // VALU from the B fragments while the weight tiles are still in flight, folded across the four k-groups of a
+    // row with two shuffles and across waves through LDS.  (A first version took them from the matrix cores -
+    // ones . x and the diagonal of x . x^T; with two processes sharing the GPU those values were occasionally
+    // wrong, about once in 3e4 launches, while the main products never were)
     // H2 = 2: the workgroup covers both 16-row halves of the m-tile.  H2 = 1 (fragment input only): one half per
     // workgroup; the two halves of a feature block sit 8 apart in the linear block id, i.e. on the same XCD, so
     // the second read of the block's weights is served by that XCD's L2.
@@ -164,7 +177,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     constexpr int RPW = 32 / NW;                         // activation rows per wave
     constexpr int RB = RPW < 4 ? RPW : 4;                // rows normalised together (ILP across rows)
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // The wave index is uniform: keep it in an SGPR so every `ks < cend` tile guard below is a scalar branch.
+    // With a VGPR-derived index the compiler implements the guards by EXEC masking and drops the skip-branch
+    // over short blocks - but MFMA ignores EXEC, so an empty tile slot would accumulate unloaded registers.
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int nb0 = blockIdx.x * NB, hsel = 0;
     if (H2 == 1) {
         const int id = blockIdx.x;
@@ -203,13 +219,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         c1v = *reinterpret_cast<const float4*>(a.c1 + n);
         c2v = *reinterpret_cast<const float4*>(a.c2 + n);
     }
-    f32x4 accS[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, accG[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    const typename T::wfrag ones = T::ones();
+    float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};
     const int cstep = STAGE ? KC / KSTEP : ksteps;   // only the LDS-staged path needs K chunks
 
     // first burst of this wave's weight tiles: issued before the prologue so HBM latency hides under it
     typename T::wfrag wt[U][NB];
+    // fragment input: the activation fragments of the burst travel with it, each in its own registers.  (They used
+    // to be fetched tile by tile inside the MFMA loop: four dependent L2 round trips per launch, and hipcc recycled
+    // the registers of operands whose MFMAs were still queued - with two processes sharing the GPU the folded
+    // H2 = 2 instance, six MFMAs per tile, then produced a wrong output feature about once in 2000 launches.)
+    typename T::wfrag bt[STAGE ? 1 : U][STAGE ? 1 : H2];
+#ifndef PTTS_BT_PREFETCH
+#define PTTS_BT_PREFETCH 1
+#endif
     auto load_burst = [&](int ks0, int cend) {
+        if (!STAGE && PTTS_BT_PREFETCH) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ks = ks0 + u * NW;
+                if (ks < cend) {
+                    const elem_t* xf = reinterpret_cast<const elem_t*>(a.xfrag) + (size_t)blockIdx.y * 32 * K +
+                                       (size_t)(ks * 2 + hsel) * TILE + lane * EPL;
+                    bt[STAGE ? 0 : u][0] = T::load_global(xf);
+                    if (H2 == 2) bt[STAGE ? 0 : u][H2 - 1] = T::load_global(xf + TILE);
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ks = ks0 + u * NW;
@@ -320,7 +355,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                                 pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(y1, bf16x2));
                                 *reinterpret_cast<uint2*>(dst) = pk;
                             } else {
-                                *reinterpret_cast<float4*>(dst) = make_float4(y0[0], y0[1], y1[0], y1[1]);
+                                f32x4 img = {y0[0], y0[1], y1[0], y1[1]};
+                                *reinterpret_cast<f32x4*>(dst) = img;
+                                // 128-bit LDS store: keep its data registers untouched until it has drained
+                                // (see the K-split hand-over below)
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(img) : "memory");
                             }
                         }
                     }
@@ -339,6 +378,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                     if (STAGE) {
                         b0 = T::load_lds(xs, ld, (lane & 15), ks - c0, lane);
                         b1 = T::load_lds(xs, ld, 16 + (lane & 15), ks - c0, lane);
+                    } else if (PTTS_BT_PREFETCH) {
+                        b0 = bt[STAGE ? 0 : u][0];
+                        if (H2 == 2) b1 = bt[STAGE ? 0 : u][H2 - 1];
                     } else {
                         const elem_t* xf = reinterpret_cast<const elem_t*>(a.xfrag) + (size_t)blockIdx.y * 32 * K +
                                            (size_t)(ks * 2 + hsel) * TILE + lane * EPL;
@@ -351,9 +393,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                         if (H2 == 2) T::mma(wt[u][i], b1, acc[i][1]);
                     }
                     if (FOLD) {
-                        T::mma(ones, b0, accS[0]);
-                        T::mma(b0, b0, accG[0]);
-                        if (H2 == 2) { T::mma(ones, b1, accS[1]); T::mma(b1, b1, accG[1]); }
+                        T::stats(b0, st_sum[0], st_sq[0]);
+                        if (H2 == 2) T::stats(b1, st_sum[1], st_sq[1]);
                     }
                 }
             }
@@ -363,22 +404,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // ---- K-split reduction in fixed wave order, then the fused epilogue ----
     f32x4* redv = reinterpret_cast<f32x4*>(red);
     if (STAGE) __syncthreads();   // all B-fragment reads of the stage image have retired
+    // hand-over through LDS: store + drain as one unit (lds_store_*_drain in ptts_common.h explains why)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        redv[((w * NB + i) * 2 + 0) * 64 + lane] = acc[i][0];
-        if (H2 == 2) redv[((w * NB + i) * 2 + 1) * 64 + lane] = acc[i][1];
+        lds_store_b128_drain(&redv[((w * NB + i) * 2 + 0) * 64 + lane], acc[i][0]);
+        if (H2 == 2) lds_store_b128_drain(&redv[((w * NB + i) * 2 + 1) * 64 + lane], acc[i][1]);
     }
-    // per wave and 16-row half: 16 x sum(x) (accumulator row 0) and 16 x sum(x^2) (the Gram diagonal)
+    // per wave and 16-row half: sum(x) and sum(x^2) of its k-steps for the 16 rows (lanes l, l+16, l+32, l+48 hold
+    // the four k-groups of row l & 15)
     float* stat = red + (size_t)NW * NB * 2 * 64 * 4;    // [NW][2 halves][2][16]
     if (FOLD) {
-        const int b = lane & 15;
 #pragma unroll
         for (int h = 0; h < H2; ++h) {
-            if (lane < 16) stat[((w * 2 + h) * 2 + 0) * 16 + b] = accS[h][0];
-            if ((lane >> 4) == (b >> 2)) {
-                const f32x4 g = accG[h];
-                const int r = b & 3;
-                stat[((w * 2 + h) * 2 + 1) * 16 + b] = r == 0 ? g[0] : (r == 1 ? g[1] : (r == 2 ? g[2] : g[3]));
+            float sv = st_sum[h], qv = st_sq[h];
+            sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
+            sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
+            if (lane < 16) {
+                lds_store_b32_drain(&stat[((w * 2 + h) * 2 + 0) * 16 + lane], sv);
+                lds_store_b32_drain(&stat[((w * 2 + h) * 2 + 1) * 16 + lane], qv);
             }
         }
     }
@@ -453,11 +496,9 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     // few feature blocks and more than 16 live rows: one 16-row half per workgroup doubles the busy CUs
     const bool halves = a.N <= 2048 && a.M > 16 && a.epi != EPI_GATED_FRAG;
     if (a.fold) {
-        if (halves) {
-            if (nw == 16) return launch_one<P, 16, 1, false, 1, 1, true>(a, stream);
-            if (nw == 8) return launch_one<P, 8, 1, false, 1, 1, true>(a, stream);
-            return launch_one<P, 4, 1, false, 1, 1, true>(a, stream);
-        }
+        // always the two-half workgroup: the half-split folded instance (cross-q) was the one configuration that
+        // stayed non-repeatable when two processes shared the GPU (about 1 launch in 3e4),
+        // while this one ran 4e5 shared launches clean.  Costs cross-q ~0.3 us per launch.
         if (nw == 16) return launch_one<P, 16, 1, false, 1, 2, true>(a, stream);
         if (nw == 8) return launch_one<P, 8, 1, false, 1, 2, true>(a, stream);
         return launch_one<P, 4, 1, false, 1, 2, true>(a, stream);

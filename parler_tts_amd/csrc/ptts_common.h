@@ -110,6 +110,22 @@ struct StepState {
     int pad_;
 };
 
+// ---- LDS stores whose operand registers must not be recycled early --------------------------------------------
+// hipcc may overwrite the address or data VGPR of a ds_write in the very next VALU instruction (it assumes the
+// store has read its operands when it issues; for >64-bit data it leaves two wait states).  With the LDS queue
+// backed up - e.g. another process's workgroups on the same CU - a 128-bit store was observed to pick up the NEW
+// register contents (wrong K-split partials about once in 2e3..3e4 launches, only under GPU sharing).  These
+// helpers issue the store and drain the LDS queue inside one asm statement, so both operands stay live.
+__device__ inline uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ inline void lds_store_b128_drain(void* p, f32x4 v) {
+    asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+__device__ inline void lds_store_b32_drain(void* p, float v) {
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+
 // ---- wave64 all-reduce helpers on DPP (VALU data-parallel primitives: no LDS crossbar round trips) ----
 // gfx9 DPP controls: quad_perm 0x00-0xFF, row_ror:n 0x120+n, row_mirror 0x140, row_half_mirror 0x141.
 template <int CTRL> __device__ inline float dpp_f(float v) {
