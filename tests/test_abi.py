@@ -118,3 +118,17 @@ def test_weight_norm_folding():
                             "b.parametrizations.weight.original0": g, "b.parametrizations.weight.original1": v})
     assert torch.allclose(out["a.weight"], ref, atol=1e-6) and torch.allclose(out["b.weight"], ref, atol=1e-6)
     assert "a.bias" in out and "a.weight_g" not in out
+
+
+def test_no_mfma_is_guarded_by_exec_masking_only():
+    """MFMA ignores EXEC: a tile guard that hipcc lowers to s_and_saveexec without a skip branch would let the MFMA
+    run on unloaded registers.  tools/check_mfma_guards.py compiles the kernels to ISA and looks for that pattern."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_mfma_guards", os.path.join(root, "tools", "check_mfma_guards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    srcs = [os.path.join(root, "parler_tts_amd", "csrc", f) for f in ("gemm.hip", "conv.hip")]
+    assert mod.main(srcs) == 0
