@@ -355,11 +355,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                                 pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(y1, bf16x2));
                                 *reinterpret_cast<uint2*>(dst) = pk;
                             } else {
-                                f32x4 img = {y0[0], y0[1], y1[0], y1[1]};
-                                *reinterpret_cast<f32x4*>(dst) = img;
-                                // 128-bit LDS store: keep its data registers untouched until it has drained
-                                // (see the K-split hand-over below)
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(img) : "memory");
+                                // 128-bit LDS store: issued with its drain (ptts_common.h: lds_store_b128_drain)
+                                lds_store_b128_drain(dst, f32x4{y0[0], y0[1], y1[0], y1[1]});
                             }
                         }
                     }
