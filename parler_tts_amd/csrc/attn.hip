@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int NWAVES = 8;
-constexpr int UNR = 4;
+constexpr int UNR = 4;     // measured: 2, 4 and 8 tiles per burst stream equally fast
 
 template <typename P> struct KVLoad;
 template <> struct KVLoad<PBF16> {
@@ -88,8 +88,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         for (int u = 0; u < UNR; ++u) {
             int tok = (t0 + u * NWAVES) * TPW + tt;
             if (tok > S - 1) tok = S - 1;
-            buf[u] = *reinterpret_cast<const raw_t*>(pool + (size_t)pages[tok >> 6] * page_elems + head_off + kv_add +
-                                                     (size_t)(tok & 63) * PTTS_HEAD_DIM);
+            const raw_t* src = reinterpret_cast<const raw_t*>(pool + (size_t)pages[tok >> 6] * page_elems + head_off + kv_add +
+                                                              (size_t)(tok & 63) * PTTS_HEAD_DIM);
+            // the cache is read exactly once per step: non-temporal loads keep 170 MB per launch from sweeping the L2s
+            // (measured 34.4 -> 31.3 us per launch, decode pass -7 %)
+            buf[u] = __builtin_nontemporal_load(src);
         }
     };
     auto score_burst = [&](const raw_t (&buf)[UNR], int t0) {
