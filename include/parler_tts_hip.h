@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 3
+#define PTTS_ABI_VERSION 4
 
 enum { PTTS_DTYPE_F32 = 0, PTTS_DTYPE_BF16 = 1 };
 
@@ -90,6 +90,12 @@ int ptts_weights_ready(ptts_engine* e);
  *      position bias gathered by the host (index j - i + T - 1).  out: [B][T][enc_hidden] fp32. ---- */
 int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_ids, const int32_t* attention_mask,
                    const float* rel_bias, float* out, void* stream);
+
+/* Pre-embedded prompts (`prompt_hidden_states`, modeling_parler_tts.py:839-840; takes precedence over
+ * `prompt_input_ids` as at :2476): embeds [B_eff][P][hidden] fp32, consumed by the NEXT ptts_prefill instead of
+ * embed_prompts[prompt_ids] (prompt_ids may then be NULL) and kept alive by the caller until that prefill has
+ * completed; NULL restores the id lookup. */
+int ptts_set_prompt_embeds(ptts_engine* e, const float* embeds);
 
 /* ---- prefill: everything generate() does before the token loop (modeling_parler_tts.py:2467-2537)
  *      plus the first forward pass over the prompt (decoder forward M:794-978 with P+1 positions):

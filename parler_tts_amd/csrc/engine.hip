@@ -138,6 +138,7 @@ struct ptts_engine {
     const long long* pattern = nullptr;
     long long* raw_ids = nullptr;
     const long long* prompt_ids = nullptr;
+    const float* prompt_embeds = nullptr;   // one-shot: set by ptts_set_prompt_embeds, consumed by the next prefill
     int host_pos = 0, host_cur = 0;
     // work stream used when the caller hands us the (uncapturable) legacy NULL stream
     hipStream_t own_stream = nullptr;
@@ -356,7 +357,7 @@ EmbedArgs embed_args(ptts_engine* e) {
     EmbedArgs a;
     a.tables = e->embed_tokens; a.rows = e->cfg.vocab + 1; a.K = e->cfg.codebooks; a.D = e->cfg.hidden;
     a.pos_table = e->pos_table; a.tok_in = e->tok_in; a.prompt_table = e->embed_prompts;
-    a.prompt_ids = e->prompt_ids; a.P = e->P; a.state = e->state; a.x = e->x;
+    a.prompt_ids = e->prompt_ids; a.prompt_embeds = e->prompt_embeds; a.P = e->P; a.state = e->state; a.x = e->x;
     a.xfrag = e->fold_ln ? e->x_frag : nullptr;
     return a;
 }
@@ -837,7 +838,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     if (B <= 0 || (B_eff != B && B_eff != 2 * B) || B_eff > c.max_batch) return fail(PTTS_E_INVALID, "B=%d B_eff=%d max_batch=%d", B, B_eff, c.max_batch);
     if (T <= 0 || T > c.max_desc_len || P < 0 || P > c.max_prompt_len || L < 2 || L > c.max_length)
         return fail(PTTS_E_INVALID, "T=%d P=%d L=%d outside the engine limits (%d, %d, %d)", T, P, L, c.max_desc_len, c.max_prompt_len, c.max_length);
-    if (P > 0 && !prompt_ids) return fail(PTTS_E_INVALID, "prompt_ids missing");
+    if (P > 0 && !prompt_ids && !e->prompt_embeds) return fail(PTTS_E_INVALID, "prompt_ids missing");
     if (start_len < 1 || start_len >= L) return fail(PTTS_E_INVALID, "start_len=%d must be in [1, L)", start_len);
     hipStream_t s;
     PTTS_TRY(enter_stream(e, stream, &s));
@@ -894,6 +895,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     HIP_TRY(init_tokens_launch(e->raw_ids, e->pattern, e->tok_in, B * c.codebooks, B_eff * c.codebooks, L, start_len - 1, s));
     e->use_force = false;
     e->prefilled = true;
+    e->prompt_embeds = nullptr;       // one-shot
     return leave_stream(e, stream, s);
 }
 
@@ -973,6 +975,12 @@ int ptts_pool_info(ptts_engine* e, int32_t* n_pages, int32_t* max_blocks, int64_
     if (n_pages) *n_pages = e->self_pages;
     if (max_blocks) *max_blocks = e->self_blocks;
     if (page_bytes) *page_bytes = (int64_t)e->cfg.layers * 2 * e->cfg.heads * PTTS_PAGE_TOKENS * PTTS_HEAD_DIM * (int64_t)e->esz;
+    return PTTS_OK;
+}
+
+int ptts_set_prompt_embeds(ptts_engine* e, const float* embeds) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    e->prompt_embeds = embeds;
     return PTTS_OK;
 }
 

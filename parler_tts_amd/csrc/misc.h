@@ -10,6 +10,7 @@ struct EmbedArgs {
     const int* tok_in = nullptr;         // [B*K] ids to feed (delay pattern already applied)
     const void* prompt_table = nullptr;  // [prompt_vocab][D]
     const long long* prompt_ids = nullptr;  // [B][P]
+    const float* prompt_embeds = nullptr;   // [B][P][D] fp32 pre-embedded prompts (override the table lookup), or null
     int P = 0;
     const StepState* state = nullptr;
     float* x = nullptr;                  // [B][D] residual stream

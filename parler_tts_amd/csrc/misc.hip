@@ -66,12 +66,13 @@ __global__ void embed_prompt_kernel(EmbedArgs a) {
     typedef typename P::elem_t elem_t;
     const int b = blockIdx.x;
     const int pos = a.state->pos;
-    const long long tok = a.prompt_ids[(size_t)b * a.P + pos];
-    const elem_t* row = reinterpret_cast<const elem_t*>(a.prompt_table) + (size_t)tok * a.D;
     const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)pos * a.D;
     elem_t* xf = a.xfrag ? reinterpret_cast<elem_t*>(a.xfrag) + (size_t)(b >> 5) * 32 * a.D : nullptr;
+    const float* pre = a.prompt_embeds ? a.prompt_embeds + ((size_t)b * a.P + pos) * a.D : nullptr;
+    const elem_t* row = pre ? nullptr
+                            : reinterpret_cast<const elem_t*>(a.prompt_table) + (size_t)a.prompt_ids[(size_t)b * a.P + pos] * a.D;
     for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-        const float v = from_elem<P>(row[d]) + from_elem<P>(ptab[d]);
+        const float v = (pre ? pre[d] : from_elem<P>(row[d])) + from_elem<P>(ptab[d]);
         a.x[(size_t)b * a.D + d] = v;
         if (xf) xf[frag_off<P>(b & 31, d)] = to_elem<P>(v);
     }

@@ -167,11 +167,14 @@ class HipEngine:
         torch.cuda.current_stream().synchronize()   # `codes` may be a temporary
         return out
 
-    def prefill(self, B, B_eff, enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, start_len):
+    def prefill(self, B, B_eff, enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, start_len,
+                prompt_embeds=None):
         T = enc_states.shape[1]
-        P = 0 if prompt_ids is None else prompt_ids.shape[1]
+        P = prompt_embeds.shape[1] if prompt_embeds is not None else (0 if prompt_ids is None else prompt_ids.shape[1])
         L = pattern.shape[1]
-        self._keep = (enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids)  # engine holds raw pointers
+        self._keep = (enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, prompt_embeds)  # raw pointers
+        if prompt_embeds is not None:      # pre-embedded prompts override the id lookup for this prefill (M:2476)
+            _hip.check(self.lib.ptts_set_prompt_embeds(self.handle, _ptr(prompt_embeds)))
         _hip.check(self.lib.ptts_prefill(self.handle, B, B_eff, T, P, L, _ptr(enc_states), _ptr(attention_mask),
                                          _ptr(prompt_ids), _ptr(prompt_mask), _ptr(pattern), _ptr(raw_ids), start_len,
                                          _stream()))
@@ -380,11 +383,11 @@ class ParlerTTSForConditionalGeneration:
         if logits_processor or stopping_criteria:
             raise NotImplementedError("custom logits processors / stopping criteria are not wired to the device loop")
         allowed = {"input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "encoder_outputs",
-                   "return_raw_ids"}
-        unsupported = {"prompt_hidden_states", "decoder_input_ids", "input_values", "decoder_attention_mask"}
+                   "prompt_hidden_states", "return_raw_ids"}
+        unsupported = {"decoder_input_ids", "input_values", "decoder_attention_mask"}
         for k in model_kwargs:
             if k in unsupported:
-                raise NotImplementedError(f"`{k}` (audio prompts / pre-embedded prompts) is a SURVEY 8(f) 'next' row")
+                raise NotImplementedError(f"`{k}` (audio prompts / decoder prefixes) is a SURVEY 8(f) 'next' row")
             if k not in allowed:
                 raise ValueError(f"The following `model_kwargs` are not used by the model: ['{k}']")
         if gen.pad_token_id is None and gen.eos_token_id is not None:   # M:2432-2442
@@ -408,7 +411,15 @@ class ParlerTTSForConditionalGeneration:
         attention_mask = attention_mask.to(dev)
         prompt_ids = model_kwargs.get("prompt_input_ids")
         prompt_mask = model_kwargs.get("prompt_attention_mask")
-        P = 0 if prompt_ids is None else prompt_ids.shape[1]
+        # pre-embedded prompts win over ids: the reference embeds ids only when no hidden states came in (M:2476-2480)
+        prompt_embeds = model_kwargs.get("prompt_hidden_states")
+        if prompt_embeds is not None:
+            if prompt_embeds.dim() != 3 or prompt_embeds.shape[0] != B or prompt_embeds.shape[2] != dec.hidden_size:
+                raise ValueError(f"prompt_hidden_states must be [batch {B}, prompt_len, {dec.hidden_size}], got {tuple(prompt_embeds.shape)}")
+            prompt_ids = None
+            P = prompt_embeds.shape[1]
+        else:
+            P = 0 if prompt_ids is None else prompt_ids.shape[1]
         use_cfg = gen.guidance_scale is not None and gen.guidance_scale > 1
         B_eff = 2 * B if use_cfg else B
         # 5./6. start ids and max_length (M:2490-2527)
@@ -452,9 +463,12 @@ class ParlerTTSForConditionalGeneration:
             amask32 = torch.cat([amask32, torch.zeros_like(amask32)], dim=0)
         pids = None if prompt_ids is None else prompt_ids.to(dev, torch.int64)
         pmask32 = None if prompt_mask is None else prompt_mask.to(dev, torch.int32)
+        pemb = None if prompt_embeds is None else prompt_embeds.to(dev, torch.float32)
         if use_cfg:
             pids = None if pids is None else pids.repeat(2, 1)
             pmask32 = None if pmask32 is None else pmask32.repeat(2, 1)
+            pemb = None if pemb is None else pemb.repeat(2, 1, 1)                            # M:2115-2116
+        pemb = None if pemb is None else pemb.contiguous()
         enc = enc.contiguous()
         amask32 = amask32.contiguous()
         pids = None if pids is None else pids.contiguous()
@@ -474,7 +488,7 @@ class ParlerTTSForConditionalGeneration:
         sp.guidance_scale = float(gen.guidance_scale) if use_cfg else 1.0
         sp.top_p = float(gen.top_p) if (gen.top_p is not None and 0.0 < gen.top_p < 1.0) else 1.0
         sp.seed = int(gen.seed if gen.seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len)
+        eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len, prompt_embeds=pemb)
         t_dec = _tick()
         # ---- the hot loop: state lives on the device, the host only polls for "all rows finished" ----
         remaining = L - start_len

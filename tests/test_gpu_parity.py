@@ -774,3 +774,25 @@ def test_repeatable_while_another_process_uses_the_gpu(hip):
         out, _ = load.communicate(timeout=300)
     assert load.returncode == 0, out
     assert "equal to pass 0: False" not in out, out
+
+
+def test_prompt_hidden_states_equal_embedded_prompt_ids(hip):
+    """`prompt_hidden_states` (pre-embedded prompts, M:839-840) take precedence over `prompt_input_ids` (M:2476) and
+    must give exactly what the id lookup gives when they ARE the embedded ids (fp32 mode: the table is not rounded)."""
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, "fp32")
+    _, sd = state_dict_for("tiny_greedy", meta, parts=("text_encoder", "decoder", "audio_encoder"))
+    desc, amask, prompt, pmask = case_inputs(f)
+    kw = dict(encoder_outputs=(torch.from_numpy(f["enc_t5"]),), attention_mask=amask, do_sample=False,
+              max_length=int(f["max_length"]), return_raw_ids=True)
+    a = model.generate(prompt_input_ids=prompt, **kw)
+    emb = torch.nn.functional.embedding(prompt, sd["embed_prompts.weight"].float())
+    b = model.generate(prompt_hidden_states=emb, **kw)
+    c = model.generate(prompt_hidden_states=emb, prompt_input_ids=torch.zeros_like(prompt), **kw)   # ids ignored
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert np.array_equal(a[0].cpu().numpy(), f["codes"])
+    rnd = torch.randn(emb.shape, generator=torch.Generator().manual_seed(5)) * 2.0
+    d = model.generate(prompt_hidden_states=rnd, **kw)               # and they are really used
+    assert not torch.equal(a, d)
+    with pytest.raises(ValueError):
+        model.generate(prompt_hidden_states=emb[:, :, :-1], **kw)
