@@ -137,6 +137,17 @@ typedef struct ptts_sampling {
  *      self-attention kernels (read back with ptts_profile_read). ---- */
 int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, int32_t profile_every, void* stream);
 
+/* One decode step in two halves, for callers that edit the scores in between (custom LogitsProcessor lists,
+ * modeling_parler_tts.py:2561-2567, applied inside the third-party greedy_search / sample before the warpers):
+ *   ptts_forward_step : embed -> decoder layers -> LM heads; the logits [B_eff*K][Vp] (Vp = vocab rounded up to 16)
+ *                       are the device buffer ptts_last_logits returns and may be overwritten in place
+ *   ptts_select_step  : the selection half of ptts_decode_steps on those logits (guidance combine, temperature /
+ *                       top-k / top-p, argmax or draw, pad-out, EOS latch, delay-pattern feed, state advance)
+ * Under guidance the buffer holds the conditional rows first, then the unconditional ones; writing the same
+ * processed scores to both halves makes the built-in combine return them unchanged. */
+int ptts_forward_step(ptts_engine* e, void* stream);
+int ptts_select_step(ptts_engine* e, const ptts_sampling* sp, void* stream);
+
 /* Loop state (host copy; synchronises `stream`): cur_len, unfinished rows, the column count at which
  * every row had finished (0 = not yet), steps run. */
 typedef struct ptts_state {

@@ -311,6 +311,7 @@ def generate_ids(
     record_logits: int = 0,
     forced_tokens: Optional[Dict[int, torch.Tensor]] = None,
     step_times: Optional[list] = None,
+    logits_processor: Optional[list] = None,
 ) -> Dict[str, torch.Tensor]:
     """The hot loop: M:2530-2537 (delay mask) + prepare_inputs_for_generation M:2081-2148 +
     forward M:1927-2079 + the third-party greedy/sample step.
@@ -359,6 +360,8 @@ def generate_ids(
                                  prompt_h if cache.length == 0 else None, pmask, cache)[:, -1, :]
         if use_cfg:
             logits = cfg_combine(logits, guidance_scale)
+        for proc in (logits_processor or []):      # user processors follow the guidance processor (M:2556-2567), before the warpers
+            logits = proc(ids, logits)
         if step < record_logits:
             step_logits.append(logits.clone())
         if do_sample:

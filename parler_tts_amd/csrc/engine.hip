@@ -134,6 +134,7 @@ struct ptts_engine {
     void *t5_afrag = nullptr, *t5_ffrag = nullptr;
     // per-call
     bool prefilled = false;
+    bool half_pending = false;   // ptts_forward_step ran, ptts_select_step has not yet
     int B = 0, B_eff = 0, T = 0, P = 0, L = 0;
     const long long* pattern = nullptr;
     long long* raw_ids = nullptr;
@@ -362,25 +363,26 @@ EmbedArgs embed_args(ptts_engine* e) {
     return a;
 }
 
-int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool profile) {
+// forward half of a decode step: embed -> layers -> final LayerNorm + LM heads -> logits [B_eff][K][Vp]
+int run_forward_half(ptts_engine* e, hipStream_t s, bool profile) {
     const ptts_config& c = e->cfg;
-    EventPair* step_ev = nullptr;
-    if (profile && e->ev_used < e->ev_pool.size()) {
-        step_ev = &e->ev_pool[e->ev_used++];
-        step_ev->kind = 1; step_ev->bytes = 0;
-        HIP_TRY(hipEventRecord(step_ev->a, s));
-    }
     DBG_GATE(e);
     HIP_TRY(embed_codebooks_launch(embed_args(e), e->B_eff, e->dt, s));
     PTTS_TRY(run_layers(e, s, profile));
     DBG_GATE(e);
-    // final LayerNorm (M:959) + the K LM heads (M:1143) -> logits [B_eff][K][Vp]
+    // final LayerNorm (M:959) + the K LM heads (M:1143)
     GemmArgs g;
     g.W = e->heads.ptr; g.N = c.codebooks * e->Vp; g.K = c.hidden; g.M = e->B_eff;
     g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = c.hidden; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.eps = 1e-5f;
     use_fold(e, &g, e->heads_f, 3);
     g.epi = EPI_ROWMAJOR; g.out = e->logits; g.ldo = c.codebooks * e->Vp;
     PTTS_TRY(launch_gemm(e, g, s));
+    return PTTS_OK;
+}
+
+// selection half: warpers / argmax / draw, pad-out, EOS latch, delay-pattern feed, loop-state advance
+int run_select_half(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
+    const ptts_config& c = e->cfg;
     SelectArgs sa;
     sa.logits = e->logits; sa.rows = e->B * c.codebooks; sa.V = e->Vp; sa.vocab = c.vocab; sa.L = e->L; sa.state = e->state;
     sa.raw_ids = e->raw_ids; sa.pattern = e->pattern; sa.unfinished = e->unfinished; sa.unf_count = e->unf_count;
@@ -389,6 +391,18 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
     sa.temperature = sp.temperature; sa.guidance = sp.guidance_scale; sa.seed = sp.seed;
     sa.top_p = (sp.top_p > 0.f && sp.top_p < 1.f) ? sp.top_p : 1.0f;
     HIP_TRY(select_launch(sa, s));   // the last row to finish also advances pos / cur_len / step_count
+    return PTTS_OK;
+}
+
+int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool profile) {
+    EventPair* step_ev = nullptr;
+    if (profile && e->ev_used < e->ev_pool.size()) {
+        step_ev = &e->ev_pool[e->ev_used++];
+        step_ev->kind = 1; step_ev->bytes = 0;
+        HIP_TRY(hipEventRecord(step_ev->a, s));
+    }
+    PTTS_TRY(run_forward_half(e, s, profile));
+    PTTS_TRY(run_select_half(e, sp, s));
     if (step_ev) HIP_TRY(hipEventRecord(step_ev->b, s));
     return PTTS_OK;
 }
@@ -895,6 +909,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     HIP_TRY(init_tokens_launch(e->raw_ids, e->pattern, e->tok_in, B * c.codebooks, B_eff * c.codebooks, L, start_len - 1, s));
     e->use_force = false;
     e->prefilled = true;
+    e->half_pending = false;
     e->prompt_embeds = nullptr;       // one-shot
     return leave_stream(e, stream, s);
 }
@@ -902,6 +917,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
 int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, int32_t profile_every, void* stream) {
     if (!e || !sp) return fail(PTTS_E_INVALID, "null argument");
     if (!e->prefilled) return fail(PTTS_E_STATE, "ptts_prefill has not run");
+    if (e->half_pending) return fail(PTTS_E_STATE, "a forward half-step is pending: call ptts_select_step first");
     if (sp->do_sample && !(sp->temperature > 0.f)) return fail(PTTS_E_INVALID, "temperature must be > 0");
     if (sp->guidance_scale > 1.0f && e->B_eff != 2 * e->B) return fail(PTTS_E_INVALID, "guidance needs B_eff = 2B");
     hipStream_t s;
@@ -932,6 +948,33 @@ int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, 
         e->host_pos += 1;
         e->host_cur += 1;
     }
+    return leave_stream(e, stream, s);
+}
+
+int ptts_forward_step(ptts_engine* e, void* stream) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    if (!e->prefilled) return fail(PTTS_E_STATE, "ptts_prefill has not run");
+    if (e->half_pending) return fail(PTTS_E_STATE, "ptts_select_step must follow ptts_forward_step");
+    if (e->host_cur >= e->L) return fail(PTTS_E_STATE, "max_length reached");
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
+    e->dbg_count = 0;
+    PTTS_TRY(run_forward_half(e, s, false));
+    e->half_pending = true;
+    return leave_stream(e, stream, s);
+}
+
+int ptts_select_step(ptts_engine* e, const ptts_sampling* sp, void* stream) {
+    if (!e || !sp) return fail(PTTS_E_INVALID, "null argument");
+    if (!e->half_pending) return fail(PTTS_E_STATE, "ptts_forward_step has not run");
+    if (sp->do_sample && !(sp->temperature > 0.f)) return fail(PTTS_E_INVALID, "temperature must be > 0");
+    if (sp->guidance_scale > 1.0f && e->B_eff != 2 * e->B) return fail(PTTS_E_INVALID, "guidance needs B_eff = 2B");
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
+    PTTS_TRY(run_select_half(e, *sp, s));
+    e->half_pending = false;
+    e->host_pos += 1;
+    e->host_cur += 1;
     return leave_stream(e, stream, s);
 }
 

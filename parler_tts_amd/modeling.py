@@ -201,6 +201,25 @@ class HipEngine:
             raise RuntimeError(f"hipMemcpy failed: {rc}")
         return out[:, :V].contiguous()
 
+    def forward_step(self) -> None:
+        _hip.check(self.lib.ptts_forward_step(self.handle, _stream()))
+
+    def select_step(self, sampling: _hip.PttsSampling) -> None:
+        _hip.check(self.lib.ptts_select_step(self.handle, C.byref(sampling), _stream()))
+
+    def set_logits(self, scores: torch.Tensor) -> None:
+        """Overwrite the first rows of the engine's logits buffer with `scores` [rows][vocab] (processed scores)."""
+        lp, pp = C.c_void_p(), C.c_void_p()
+        _hip.check(self.lib.ptts_last_logits(self.handle, C.byref(lp), C.byref(pp)))
+        V = self.cfg.decoder.vocab_size
+        Vp = (V + 15) // 16 * 16
+        buf = torch.full((scores.shape[0], Vp), float("-inf"), device=self.device, dtype=torch.float32)
+        buf[:, :V] = scores.to(self.device, torch.float32)
+        torch.cuda.current_stream().synchronize()
+        rc = _hipMemcpyDtoD(lp.value, buf.data_ptr(), buf.numel() * 4)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed: {rc}")
+
     def set_forced_tokens(self, tokens: Optional[torch.Tensor]) -> None:
         if tokens is None:
             _hip.check(self.lib.ptts_set_forced_tokens(self.handle, None, 0))
@@ -380,8 +399,8 @@ class ParlerTTSForConditionalGeneration:
         user_max_length = kwargs.get("max_length")
         model_kwargs = gen.update(**kwargs)
         gen.validate()
-        if logits_processor or stopping_criteria:
-            raise NotImplementedError("custom logits processors / stopping criteria are not wired to the device loop")
+        logits_processor = list(logits_processor) if logits_processor else []
+        stopping_criteria = list(stopping_criteria) if stopping_criteria else []
         allowed = {"input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "encoder_outputs",
                    "prompt_hidden_states", "return_raw_ids"}
         unsupported = {"decoder_input_ids", "input_values", "decoder_attention_mask"}
@@ -492,8 +511,39 @@ class ParlerTTSForConditionalGeneration:
         t_dec = _tick()
         # ---- the hot loop: state lives on the device, the host only polls for "all rows finished" ----
         remaining = L - start_len
-        chunk = 1 if streamer is not None else 128
         L_out = L
+        if logits_processor or stopping_criteria:
+            # custom processors / criteria are host callables (M:2561-2573): one step at a time, the scores pass through
+            # them between the forward half and the selection half, in the order of the third-party loop
+            # (processors on [B*K, vocab] scores after the guidance combine, then the warpers inside the select kernel)
+            V = dec.vocab_size
+            n = B * K
+            while remaining > 0:
+                eng.forward_step()
+                st = eng.state()
+                scores = eng.last_logits(B_eff * K)
+                if use_cfg:
+                    scores = scores[n:] + (scores[:n] - scores[n:]) * float(gen.guidance_scale)      # M:2556-2558
+                seen = raw_ids[:, :st.cur_len]
+                for proc in logits_processor:
+                    scores = proc(seen, scores)
+                eng.set_logits(torch.cat([scores, scores], dim=0) if use_cfg else scores)
+                eng.select_step(sp)
+                remaining -= 1
+                st = eng.state()
+                if streamer is not None:
+                    streamer.put(raw_ids[:, st.cur_len - 1].cpu())
+                if st.done_len:
+                    L_out = st.done_len
+                    break
+                if stopping_criteria:
+                    seen = raw_ids[:, :st.cur_len]
+                    stop = [c(seen, scores) for c in stopping_criteria]
+                    if any(bool(torch.as_tensor(x).all()) for x in stop):
+                        L_out = st.cur_len
+                        break
+            remaining = 0
+        chunk = 1 if streamer is not None else 128
         while remaining > 0:
             n = min(chunk, remaining)
             eng.decode_steps(n, sp, self.profile_every)

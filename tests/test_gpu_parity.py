@@ -796,3 +796,49 @@ def test_prompt_hidden_states_equal_embedded_prompt_ids(hip):
     assert not torch.equal(a, d)
     with pytest.raises(ValueError):
         model.generate(prompt_hidden_states=emb[:, :, :-1], **kw)
+
+
+def test_custom_logits_processors_and_stopping_criteria(hip):
+    """`logits_processor` / `stopping_criteria` lists (M:2561-2573): host callables applied between the forward half and
+    the selection half of every step, in the third-party loop's order.  Checked against the oracle loop with the same
+    processors (fp32 mode, bit-exact ids), an identity processor, and a criterion that stops the loop early."""
+    from oracle import cpu_ref
+
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, "fp32")
+    _, sd = state_dict_for("tiny_greedy", meta, parts=("text_encoder", "decoder", "audio_encoder"))
+    desc, amask, prompt, pmask = case_inputs(f)
+    L = int(f["max_length"])
+    enc = torch.from_numpy(f["enc_t5"])
+    kw = dict(encoder_outputs=(enc,), attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L,
+              return_raw_ids=True)
+    base = model.generate(**kw)
+    same = model.generate(logits_processor=[lambda ids, sc: sc], **kw)
+    assert torch.equal(base, same)
+
+    banned = torch.arange(0, cfg.decoder.vocab_size, 3)
+
+    def ban(ids, scores):                      # a NoBadWords-style processor
+        scores = scores.clone()
+        scores[:, banned.to(scores.device)] = float("-inf")
+        return scores
+
+    def ramp(ids, scores):                     # depends on the ids generated so far
+        return scores + 0.05 * (ids[:, -1:].to(scores.device).float() % 7) * torch.linspace(-1, 1, scores.shape[1], device=scores.device)
+
+    got = model.generate(logits_processor=[ban, ramp], **kw)
+    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, logits_processor=[ban, ramp])
+    want = cpu_ref.undelay(cfg, ref["raw_ids"], ref["pattern"])
+    assert torch.equal(got.cpu(), want)
+    assert not bool(torch.isin(got.cpu(), banned).any())
+    assert not torch.equal(got, base)
+
+    calls = []
+
+    def stop_after_8(ids, scores):
+        calls.append(ids.shape[1])
+        return ids.shape[1] >= 8
+
+    short = model.generate(stopping_criteria=[stop_after_8], **kw)
+    assert model.last_raw_ids.shape[1] == 8 and calls[-1] == 8
+    assert short.shape[-1] < base.shape[-1] or base.shape[-1] == 0
