@@ -16,7 +16,14 @@ struct AttnArgs {
     int s_cap = 0;                // LDS score capacity (>= max keys, multiple of 4)
     void* ofrag = nullptr;        // output in B-fragment order, feature count D
     int D = 0;
-    int no_page_kernel = 0;       // 1: always use the general kernel (A/B and equivalence tests)
+    int no_page_kernel = 0;
+    // single-page kernel only: `q` holds the RAW look-ahead product x.W'^T; the LayerNorm of the folded projection
+    // is applied here from per-block row statistics: q = scale * (rstd * (q - mean * c1) + c2)
+    const float* lnfix_stat = nullptr;   // [((b / 32) * blocks + block) * 32 + b % 32][2] = (sum, sum of squares)
+    int lnfix_blocks = 0;                // 16-column blocks per row (K / 16)
+    const float* lnfix_c1 = nullptr;
+    const float* lnfix_c2 = nullptr;
+    float lnfix_eps = 1e-5f, lnfix_scale = 1.0f;       // 1: always use the general kernel (A/B and equivalence tests)
 };
 
 struct FullAttnArgs {

@@ -265,11 +265,36 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
         const float bv = brow[tok];
         bs[u] = has_bias ? bv : 0.f;
     }
+    // look-ahead query: statistics partials of row b (one 16-column block per lane) and this lane's c1 / c2 slice
+    const bool lnfix = a.lnfix_stat != nullptr;
+    float st_s = 0.f, st_q = 0.f, fc1[EPL], fc2[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) { fc1[j] = 0.f; fc2[j] = 0.f; }
+    if (lnfix) {
+        const float* sp = a.lnfix_stat + ((size_t)(b >> 5) * a.lnfix_blocks * 32 + (b & 31)) * 2;
+        for (int nbk = lane; nbk < a.lnfix_blocks; nbk += 64) {
+            st_s += sp[(size_t)nbk * 64];
+            st_q += sp[(size_t)nbk * 64 + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            fc1[j] = a.lnfix_c1[h * PTTS_HEAD_DIM + c * EPL + j];
+            fc2[j] = a.lnfix_c2[h * PTTS_HEAD_DIM + c * EPL + j];
+        }
+    }
     // hipcc otherwise sinks the V loads below the score arithmetic; an empty asm use pins every load above this point
 #pragma unroll
     for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(kb[u]));
 #pragma unroll
     for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(vb[u]));
+    if (lnfix) {
+        const float K = (float)(a.lnfix_blocks * 16);
+        const float mean = wave_sum(st_s) / K;
+        const float var = fmaxf(wave_sum(st_q) / K - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + a.lnfix_eps);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) q[j] = a.lnfix_scale * (rstd * (q[j] - mean * fc1[j]) + fc2[j]);
+    }
     // scores: every lane of a token row ends up with the row's full dot product
     float sc[NT];
     float m = -INFINITY;

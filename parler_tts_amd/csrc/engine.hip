@@ -63,6 +63,7 @@ struct DecLayer {
     Packed qkv, o, cq, ckv, co, fc1, fc2;
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
     Folded qkv_f, cq_f, fc1_f;
+    void* look = nullptr;      // look-ahead weights [D][2D]: [cq_f.w | cq_f.w . o]  (see run_layers)
 };
 struct T5Layer {
     Packed qkv, o, wi, wo;
@@ -98,6 +99,11 @@ struct ptts_engine {
     bool fold_ln = false;      // LayerNorm applied after the MFMA on gamma-folded weights (default for bf16)
     bool fold_dirty = true;    // a tensor arrived since the folded copies were built
     int fold_mask = 15;
+    bool lookahead = false;    // cross-q computed inside the self-attention out-projection launch (default with the fold)
+    bool look_active = false;  // ... and usable for the current call (single-page description, fold on)
+    void* x_frag2 = nullptr;   // second fragment buffer (the out-projection reads the old rows while writing the new)
+    void* xf_cur = nullptr;    // fragment buffer that holds the current residual rows
+    float* xstat = nullptr;    // per-block row statistics of the rows the out-projection wrote
     bool no_page_kernel = false;   // PTTS_ATTN_NO_PAGE_KERNEL=1: cross-attention on the general kernel (A/B, tests)
     float *lnf_g = nullptr, *lnf_b = nullptr, *enc_proj_bias = nullptr;
     void *embed_tokens = nullptr, *pos_table = nullptr, *embed_prompts = nullptr;
@@ -252,7 +258,7 @@ int load_table(ptts_engine* e, void** dst, size_t total, size_t off, size_t n, c
 void use_fold(const ptts_engine* e, GemmArgs* g, const Folded& f, int which = 0) {
     if (!e->fold_ln) return;
     if (!(e->fold_mask & (1 << which))) return;      // PTTS_FOLD_MASK: bit 0 QKV, 1 cross-q, 2 fc1, 3 LM heads (A/B)
-    g->W = f.w; g->pro = PRO_FRAG; g->xfrag = e->x_frag; g->x = nullptr; g->fold = 1; g->c1 = f.c1; g->c2 = f.c2;
+    g->W = f.w; g->pro = PRO_FRAG; g->xfrag = e->xf_cur; g->x = nullptr; g->fold = 1; g->c1 = f.c1; g->c2 = f.c2;
 }
 
 int fold_one(ptts_engine* e, const Packed& w, const float* gamma, const float* beta, Folded* f, hipStream_t s) {
@@ -272,6 +278,11 @@ int refresh_folds(ptts_engine* e, hipStream_t s) {
         PTTS_TRY(fold_one(e, w.qkv, w.ln1_g, w.ln1_b, &w.qkv_f, s));
         PTTS_TRY(fold_one(e, w.cq, w.ln2_g, w.ln2_b, &w.cq_f, s));
         PTTS_TRY(fold_one(e, w.fc1, w.ln3_g, w.ln3_b, &w.fc1_f, s));
+        if (e->lookahead) {
+            const int D = e->cfg.hidden;
+            if (!w.look) PTTS_TRY(dev_alloc(e, &w.look, (size_t)D * 2 * D * e->esz));
+            HIP_TRY(lookahead_build_launch(w.cq_f.w, w.o.ptr, w.look, D, D, e->dt, s));
+        }
     }
     PTTS_TRY(fold_one(e, e->heads, e->lnf_g, e->lnf_b, &e->heads_f, s));
     e->fold_dirty = false;
@@ -311,30 +322,47 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
         if (ep) HIP_TRY(hipEventRecord(ep->b, s));
         // out_proj + residual (M:380, M:460)
+        const bool look = e->look_active;
         g = GemmArgs();
         g.W = w.o.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->x_frag : nullptr;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
+        if (look) {
+            // look-ahead cross-q: LN2(x + a.Wo^T).Wq^T = rstd * ((x.Wq'^T + a.(Wq'.Wo)^T) - mean * c1) + c2, so the
+            // raw product needs only the rows this launch STARTS from and its own input: extra workgroups of the same
+            // launch compute it into `q`; the updated rows go to the other fragment buffer, their per-block statistics
+            // to `xstat`, and the cross-attention kernel applies the LayerNorm when it loads q.
+            void* next = e->xf_cur == e->x_frag ? e->x_frag2 : e->x_frag;
+            g.W2 = w.look; g.N2 = D; g.K2 = 2 * D; g.xfrag_lo = e->xf_cur; g.ksplit = D / (e->dt == PTTS_DTYPE_BF16 ? 32 : 16);
+            g.out2 = e->q; g.ldo2 = D; g.xfrag_out = next; g.xstat = e->xstat;
+            e->xf_cur = next;
+        }
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
-        // LN2 + cross-attention query (M:467-471)
-        g = GemmArgs();
-        g.W = w.cq.ptr; g.N = D; g.K = D; g.M = M;
-        g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.eps = 1e-5f;
-        use_fold(e, &g, w.cq_f, 1);
-        g.epi = EPI_Q_SCALE; g.out = e->q; g.ldo = D; g.scale = scale;
-        DBG_GATE(e);
-        PTTS_TRY(launch_gemm(e, g, s));
+        if (!look) {
+            // LN2 + cross-attention query (M:467-471)
+            g = GemmArgs();
+            g.W = w.cq.ptr; g.N = D; g.K = D; g.M = M;
+            g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.eps = 1e-5f;
+            use_fold(e, &g, w.cq_f, 1);
+            g.epi = EPI_Q_SCALE; g.out = e->q; g.ldo = D; g.scale = scale;
+            DBG_GATE(e);
+            PTTS_TRY(launch_gemm(e, g, s));
+        }
         // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294)
         a = AttnArgs();
         a.q = e->q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
         a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS;
         a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = e->attn_frag; a.D = D;
         a.no_page_kernel = e->no_page_kernel ? 1 : 0;
+        if (look) {
+            a.lnfix_stat = e->xstat; a.lnfix_blocks = D / 16; a.lnfix_c1 = w.cq_f.c1; a.lnfix_c2 = w.cq_f.c2;
+            a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
+        }
         DBG_GATE(e);
         HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
         g = GemmArgs();
         g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->x_frag : nullptr;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         // LN3 + fc1 + GELU(erf) -> fragments ; fc2 + residual (M:486-492)
@@ -347,7 +375,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         PTTS_TRY(launch_gemm(e, g, s));
         g = GemmArgs();
         g.W = w.fc2.ptr; g.N = D; g.K = F; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->mlp_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->x_frag : nullptr;
+        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
     }
@@ -359,7 +387,7 @@ EmbedArgs embed_args(ptts_engine* e) {
     a.tables = e->embed_tokens; a.rows = e->cfg.vocab + 1; a.K = e->cfg.codebooks; a.D = e->cfg.hidden;
     a.pos_table = e->pos_table; a.tok_in = e->tok_in; a.prompt_table = e->embed_prompts;
     a.prompt_ids = e->prompt_ids; a.prompt_embeds = e->prompt_embeds; a.P = e->P; a.state = e->state; a.x = e->x;
-    a.xfrag = e->fold_ln ? e->x_frag : nullptr;
+    a.xfrag = e->fold_ln ? e->x_frag : nullptr;     // a step / prompt position always starts in the first buffer
     return a;
 }
 
@@ -367,6 +395,7 @@ EmbedArgs embed_args(ptts_engine* e) {
 int run_forward_half(ptts_engine* e, hipStream_t s, bool profile) {
     const ptts_config& c = e->cfg;
     DBG_GATE(e);
+    e->xf_cur = e->x_frag;
     HIP_TRY(embed_codebooks_launch(embed_args(e), e->B_eff, e->dt, s));
     PTTS_TRY(run_layers(e, s, profile));
     DBG_GATE(e);
@@ -573,6 +602,8 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->fold_ln = cfg->dtype == PTTS_DTYPE_BF16;
     if (const char* v = getenv("PTTS_LN_FOLD")) e->fold_ln = atoi(v) != 0;
     e->no_page_kernel = getenv("PTTS_ATTN_NO_PAGE_KERNEL") != nullptr;
+    e->lookahead = e->fold_ln;      // look-ahead cross-q rides on the folded LayerNorm (PTTS_LOOKAHEAD=0 switches it off)
+    if (const char* v = getenv("PTTS_LOOKAHEAD")) e->lookahead = atoi(v) != 0;
     if (const char* v = getenv("PTTS_FOLD_MASK")) e->fold_mask = atoi(v);
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     if (cfg->dac_hidden > 0) {
@@ -626,6 +657,8 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->q, sizeof(float) * rows * D);
     A(e->attn_frag, e->esz * rows * D);
     A(e->x_frag, e->esz * rows * D);
+    A(e->x_frag2, e->esz * rows * D);
+    A(e->xstat, sizeof(float) * 2 * rows * (D / 16 + 1));
     A(e->mlp_frag, e->esz * rows * F);
     A(e->logits, sizeof(float) * rows * K * e->Vp);
     A(e->probs, sizeof(float) * rows * K * e->Vp);
@@ -658,6 +691,8 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     if (he == hipSuccess) he = hipMemset(e->unf_count, 0, 4 * sizeof(int));
     if (he == hipSuccess) he = hipMemset(e->attn_frag, 0, e->esz * rows * D);
     if (he == hipSuccess) he = hipMemset(e->x_frag, 0, e->esz * rows * D);
+    if (he == hipSuccess) he = hipMemset(e->x_frag2, 0, e->esz * rows * D);
+    e->xf_cur = e->x_frag;
     if (he == hipSuccess) he = hipMemset(e->mlp_frag, 0, e->esz * rows * F);
     if (he == hipSuccess) he = hipMemset(e->x, 0, sizeof(float) * rows * D);
     if (he != hipSuccess) { ptts_destroy(e); return fail(PTTS_E_HIP, "init copies failed: %s", hipGetErrorString(he)); }
@@ -860,6 +895,8 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     drop_graph(e);
     PTTS_TRY(refresh_folds(e, s));
     e->B = B; e->B_eff = B_eff; e->T = T; e->P = P; e->L = L;
+    // the look-ahead query needs the folded projection, the single-page cross-attention kernel and bf16-size k-steps
+    e->look_active = e->lookahead && e->fold_ln && (e->fold_mask & 2) && !e->no_page_kernel && T <= PTTS_PAGE_TOKENS;
     e->pattern = (const long long*)pattern; e->raw_ids = (long long*)raw_ids; e->prompt_ids = (const long long*)prompt_ids;
     const int D = c.hidden, M = B_eff * T;
     // additive masks (M:870-879)
@@ -898,6 +935,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     for (int p = 0; p < P; ++p) {
         if (e->dbg_stop >= 0 && e->dbg_count >= e->dbg_stop) break;
         e->dbg_count++;
+        e->xf_cur = e->x_frag;
         HIP_TRY(embed_prompt_launch(embed_args(e), B_eff, e->dt, s));
         e->host_pos = p;
         PTTS_TRY(run_layers(e, s, false));

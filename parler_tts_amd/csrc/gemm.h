@@ -32,6 +32,17 @@ struct GemmArgs {
     const int* rowmask = nullptr;
     void* ofrag = nullptr;
     void* xfrag_out = nullptr;    // EPI_RESIDUAL: also store the updated rows as fragments [(M+31)/32][32*ldo]
+    float* xstat = nullptr;       // EPI_RESIDUAL: per 16-column block (sum, sum of squares) of the updated rows as the
+                                  // weight dtype rounds them: [((m-tile * N/16) + block) * 32 + row][2]
+    // second role in the same launch (fragment input, half-split grid only; "look-ahead projection"):
+    // workgroups past the first role's grid compute  out2 = [xfrag_lo | xfrag] . W2^T  (raw, row-major), i.e. a
+    // projection of the rows this launch is about to produce, from the rows it starts from and its own input
+    const void* W2 = nullptr;     // packed [N2][K2]
+    int N2 = 0, K2 = 0;
+    const void* xfrag_lo = nullptr;   // fragments of the first ksplit k-steps; the rest come from `xfrag`
+    int ksplit = 0;
+    float* out2 = nullptr;
+    int ldo2 = 0;
     int act = ACT_NONE;
     float scale = 1.0f;
     KVPool pool = {};
@@ -52,4 +63,7 @@ hipError_t fold_layernorm_launch(const void* W, void* Wf, const float* gamma, co
                                  int N, int K, int dtype, hipStream_t stream);
 // row-major fp32 [M][K] -> fragment layout of the weight dtype (test hook for the folded path)
 hipError_t rows_to_frag_launch(const float* X, void* xfrag, int M, int K, int dtype, hipStream_t stream);
+// look-ahead weights (packed [N][2K]): columns 0..K-1 = Wf (the gamma-folded projection, packed [N][K]); columns K..2K-1 =
+// Wf . Wo, Wo packed [K][K] = the residual projection whose output the folded projection would have read
+hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int N, int K, int dtype, hipStream_t stream);
 hipError_t convert_launch(const float* src, void* dst, size_t n, int dtype, hipStream_t stream);

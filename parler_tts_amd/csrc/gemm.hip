@@ -182,8 +182,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // over short blocks - but MFMA ignores EXEC, so an empty tile slot would accumulate unloaded registers.
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int nb0 = blockIdx.x * NB, hsel = 0;
+    bool role2 = false;
     if (H2 == 1) {
-        const int id = blockIdx.x;
+        int id = blockIdx.x;
+        const int ids1 = ((a.N / 16 + 7) / 8) * 16;
+        if (!STAGE && !FOLD && a.W2 && id >= ids1) {   // second role: the look-ahead product (uniform per workgroup)
+            role2 = true;
+            id -= ids1;
+            a.W = a.W2; a.N = a.N2; a.K = a.K2;
+            a.epi = EPI_ROWMAJOR; a.out = a.out2; a.ldo = a.ldo2;
+            a.bias = nullptr; a.rowmask = nullptr; a.act = ACT_NONE; a.xfrag_out = nullptr; a.xstat = nullptr;
+        }
         nb0 = (((id >> 4) << 3) + (id & 7)) * NB;
         hsel = (id >> 3) & 1;
         if (nb0 * 16 >= a.N) return;            // padding blocks of the last group of 8
@@ -229,17 +238,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // the registers of operands whose MFMAs were still queued - with two processes sharing the GPU the folded
     // H2 = 2 instance, six MFMAs per tile, then produced a wrong output feature about once in 2000 launches.)
     typename T::wfrag bt[STAGE ? 1 : U][STAGE ? 1 : H2];
-#ifndef PTTS_BT_PREFETCH
-#define PTTS_BT_PREFETCH 1
-#endif
     auto load_burst = [&](int ks0, int cend) {
-        if (!STAGE && PTTS_BT_PREFETCH) {
+        if (!STAGE) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ks = ks0 + u * NW;
                 if (ks < cend) {
-                    const elem_t* xf = reinterpret_cast<const elem_t*>(a.xfrag) + (size_t)blockIdx.y * 32 * K +
-                                       (size_t)(ks * 2 + hsel) * TILE + lane * EPL;
+                    // the second role reads its first ksplit k-steps from xfrag_lo, the rest from xfrag
+                    const bool lo = role2 && ks < a.ksplit;
+                    const int kk = role2 && !lo ? ks - a.ksplit : ks;
+                    const int ksrc = !role2 ? K : (lo ? a.ksplit * KSTEP : K - a.ksplit * KSTEP);
+                    const elem_t* xf = reinterpret_cast<const elem_t*>(lo ? a.xfrag_lo : a.xfrag) + (size_t)blockIdx.y * 32 * ksrc +
+                                       (size_t)(kk * 2 + hsel) * TILE + lane * EPL;
                     bt[STAGE ? 0 : u][0] = T::load_global(xf);
                     if (H2 == 2) bt[STAGE ? 0 : u][H2 - 1] = T::load_global(xf + TILE);
                 }
@@ -375,14 +385,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                     if (STAGE) {
                         b0 = T::load_lds(xs, ld, (lane & 15), ks - c0, lane);
                         b1 = T::load_lds(xs, ld, 16 + (lane & 15), ks - c0, lane);
-                    } else if (PTTS_BT_PREFETCH) {
+                    } else {
                         b0 = bt[STAGE ? 0 : u][0];
                         if (H2 == 2) b1 = bt[STAGE ? 0 : u][H2 - 1];
-                    } else {
-                        const elem_t* xf = reinterpret_cast<const elem_t*>(a.xfrag) + (size_t)blockIdx.y * 32 * K +
-                                           (size_t)(ks * 2 + hsel) * TILE + lane * EPL;
-                        b0 = T::load_global(xf);
-                        if (H2 == 2) b1 = T::load_global(xf + TILE);
                     }
 #pragma unroll
                     for (int i = 0; i < NB; ++i) {
@@ -449,9 +454,29 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             s[2] = rstd * (s[2] - mean * c1v.z) + c2v.z;
             s[3] = rstd * (s[3] - mean * c1v.w) + c2v.w;
         }
-        if (row >= a.M) continue;
         const int n = gated ? blockIdx.x * 16 + 4 * (ln >> 4) : (nb0 + i) * 16 + 4 * (ln >> 4);
-        epilogue<P>(a, row, n, s, s1, xres, have_res && t == tid);
+        if (row < a.M) epilogue<P>(a, row, n, s, s1, xres, have_res && t == tid);
+        if (H2 == 1 && !STAGE && !FOLD && a.xstat && a.epi == EPI_RESIDUAL) {
+            // partial LayerNorm statistics of the rows just written, over this block's 16 columns, on the values the
+            // weight dtype will hold (so that a consumer's mean subtraction matches what its MFMA multiplied)
+            float ps = 0.f, pq = 0.f;
+            if (row < a.M && have_res) {
+                const float xv[4] = {xres.x + s[0], xres.y + s[1], xres.z + s[2], xres.w + s[3]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = from_elem<P>(to_elem<P>(xv[r]));
+                    ps += v;
+                    pq = fmaf(v, v, pq);
+                }
+            }
+            ps += __shfl_xor(ps, 16); pq += __shfl_xor(pq, 16);
+            ps += __shfl_xor(ps, 32); pq += __shfl_xor(pq, 32);
+            if (ln < 16 && row < a.M) {
+                float* st2 = a.xstat + (((size_t)blockIdx.y * (a.N / 16) + nb0 + i) * 32 + 16 * hsel + ln) * 2;
+                st2[0] = ps;
+                st2[1] = pq;
+            }
+        }
     }
 }
 
@@ -465,6 +490,7 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     if (lds < red_bytes) lds = red_bytes;
     dim3 grid((a.N + 16 * NB - 1) / (16 * NB), (a.M + 31) / 32);
     if (H2 == 1) grid.x = ((grid.x + 7) / 8) * 16;     // groups of 8 blocks x 2 halves
+    if (H2 == 1 && !STAGE && !FOLD && a.W2) grid.x += ((a.N2 / 16 + 7) / 8) * 16;   // + the look-ahead role
     auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
@@ -491,7 +517,8 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     // fragment input: enough K-split that a wave streams <= ~8 tiles in one burst
     const int nw = ksteps > 64 ? 16 : (ksteps > 16 ? 8 : 4);   // <= 8 (K<=2048 bf16) / 4 tiles in flight per wave
     // few feature blocks and more than 16 live rows: one 16-row half per workgroup doubles the busy CUs
-    const bool halves = a.N <= 2048 && a.M > 16 && a.epi != EPI_GATED_FRAG;
+    // (with a second role the half-split grid is used for every M: the arithmetic must not depend on the batch size)
+    const bool halves = a.N <= 2048 && (a.M > 16 || a.W2) && a.epi != EPI_GATED_FRAG;
     if (a.fold) {
         // always the two-half workgroup: the half-split folded instance (cross-q) was the one configuration that
         // stayed non-repeatable when two processes shared the GPU (about 1 launch in 3e4),
@@ -570,6 +597,23 @@ __global__ __launch_bounds__(64) void fold_ln_kernel(const typename P::elem_t* _
     }
 }
 
+// one block = one output row n and 256 consecutive columns of the stacked matrix (runs once per weight set)
+template <typename P>
+__global__ __launch_bounds__(256) void lookahead_build_kernel(const typename P::elem_t* __restrict__ Wf,
+                                                              const typename P::elem_t* __restrict__ Wo,
+                                                              typename P::elem_t* __restrict__ out, int N, int K) {
+    const int n = blockIdx.y, jj = blockIdx.x * 256 + threadIdx.x;
+    if (jj >= 2 * K) return;
+    if (jj < K) {
+        out[wpack_off<P>(n, jj, 2 * K)] = Wf[wpack_off<P>(n, jj, K)];
+        return;
+    }
+    const int j = jj - K;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(from_elem<P>(Wf[wpack_off<P>(n, k, K)]), from_elem<P>(Wo[wpack_off<P>(k, j, K)]), acc);
+    out[wpack_off<P>(n, jj, 2 * K)] = to_elem<P>(acc);
+}
+
 template <typename P>
 __global__ void rows_to_frag_kernel(const float* __restrict__ X, typename P::elem_t* xf, int M, int K) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -598,6 +642,10 @@ int gemm_validate(const GemmArgs& a, int dtype) {
         if (a.pro == PRO_LAYERNORM && !a.beta) return -5;
     } else if (!a.xfrag) return -6;
     if (a.fold && (a.pro != PRO_FRAG || !a.c1 || !a.c2 || a.epi == EPI_GATED_FRAG)) return -10;
+    if (a.W2) {   // second role: half-split grid, fragment input, same wave count as the first role (it may need more bursts)
+        if (a.pro != PRO_FRAG || a.fold || a.epi != EPI_RESIDUAL || a.N > 2048 || !a.xfrag_lo || !a.out2) return -11;
+        if (a.K2 % kstep != 0 || a.N2 % 16 != 0 || a.ksplit <= 0 || a.ksplit >= a.K2 / kstep) return -12;
+    }
     if (a.epi == EPI_GATED_FRAG && a.N % 32 != 0) return -7;
     if ((a.epi == EPI_RESIDUAL || a.epi == EPI_Q_SCALE || a.epi == EPI_QKV_SELF) && (a.ldo % 4 != 0)) return -8;
     if ((a.epi == EPI_QKV_SELF || a.epi == EPI_KV_CROSS) && (a.D % 64 != 0 || a.N % a.D != 0)) return -9;
@@ -636,6 +684,17 @@ hipError_t fold_layernorm_launch(const void* W, void* Wf, const float* gamma, co
     else
         hipLaunchKernelGGL(fold_ln_kernel<PF32>, dim3(N / 16), dim3(64), 0, stream, (const float*)W, (float*)Wf, gamma, beta,
                            c1, c2, K);
+    return hipGetLastError();
+}
+
+hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int N, int K, int dtype, hipStream_t stream) {
+    dim3 grid((2 * K + 255) / 256, N);
+    if (dtype == PTTS_BF16)
+        hipLaunchKernelGGL(lookahead_build_kernel<PBF16>, grid, dim3(256), 0, stream, (const uint16_t*)Wf, (const uint16_t*)Wo,
+                           (uint16_t*)out, N, K);
+    else
+        hipLaunchKernelGGL(lookahead_build_kernel<PF32>, grid, dim3(256), 0, stream, (const float*)Wf, (const float*)Wo,
+                           (float*)out, N, K);
     return hipGetLastError();
 }
 

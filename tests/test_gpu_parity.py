@@ -842,3 +842,17 @@ def test_custom_logits_processors_and_stopping_criteria(hip):
     short = model.generate(stopping_criteria=[stop_after_8], **kw)
     assert model.last_raw_ids.shape[1] == 8 and calls[-1] == 8
     assert short.shape[-1] < base.shape[-1] or base.shape[-1] == 0
+
+
+def test_lookahead_cross_q_agrees_with_separate_projection(hip):
+    """Look-ahead cross-q (x.Wq' + a.(Wq'.Wo) inside the out-projection launch, LayerNorm applied by the cross-attention
+    kernel from per-block statistics) vs the separate folded projection: same model, same teacher-forced tokens."""
+    for name in ("tiny_greedy", "tiny_greedy_ragged", "tiny_cfg"):
+        a = _fresh_engine_logits(name, "bf16", {"PTTS_LOOKAHEAD": "1"})
+        b = _fresh_engine_logits(name, "bf16", {"PTTS_LOOKAHEAD": "0"})
+        assert not torch.isnan(a).any()
+        assert (a - b).abs().max().item() < 0.05, name
+        assert (a.argmax(-1) == b.argmax(-1)).float().mean().item() > 0.95, name
+    a = _fresh_engine_logits("tiny_greedy", "fp32", {"PTTS_LOOKAHEAD": "1", "PTTS_LN_FOLD": "1"})
+    b = _fresh_engine_logits("tiny_greedy", "fp32", {"PTTS_LOOKAHEAD": "0", "PTTS_LN_FOLD": "1"})
+    assert (a - b).abs().max().item() < 1e-4
