@@ -164,8 +164,10 @@ def main():
     phase = {"t5_prefill_ms": 0.0, "decode_ms": 0.0, "post_ms": 0.0}
     model.phase_times = phase
     t0 = time.perf_counter()
+    pass_codes = []            # references only (no sync, no copy): compared after the timed region
     for _ in range(args.steps):
         out = model.generate(**kw)
+        pass_codes.append(model.last_codes)
         if dist is not None:   # data-parallel plumbing: gather the codec ids of every rank (RCCL over xGMI)
             codes = model.last_codes[0].to(torch.int32)
             if dist.get_backend() != "nccl":
@@ -174,6 +176,8 @@ def main():
             dist.all_gather(gathered, codes)
     sync_all()
     dt = time.perf_counter() - t0
+    # every timed pass ran the same inputs greedily: their codec ids must be identical (bit-repeatability check)
+    repeatable = all(bool(torch.equal(c, pass_codes[0])) for c in pass_codes[1:]) if len(pass_codes) > 1 else None
     if dist is not None:
         tmax = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -207,6 +211,7 @@ def main():
             "rtf_audio_s_per_wall_s": round(audio_s / dt, 2),
             "decode_loop_tokens_per_s": round(tokens / world / max(phase["decode_ms"] / 1e3, 1e-9), 1) if phase["decode_ms"] else None,
             "phase_ms_per_step_rank0": {k: round(v / args.steps, 2) for k, v in phase.items()},
+            "passes_bit_identical_rank0": repeatable,
             "roofline": {
                 "kernel": "attn_decode_kernel (self-attention over the paged KV cache)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
