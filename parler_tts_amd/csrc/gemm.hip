@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                     const elem_t* xf = reinterpret_cast<const elem_t*>(lo ? a.xfrag_lo : a.xfrag) + (size_t)blockIdx.y * 32 * ksrc +
                                        (size_t)(kk * 2 + hsel) * TILE + lane * EPL;
                     bt[STAGE ? 0 : u][0] = T::load_global(xf);
-                    if (H2 == 2) bt[STAGE ? 0 : u][H2 - 1] = T::load_global(xf + TILE);
+                    if (H2 == 2) bt[STAGE ? 0 : u][STAGE ? 0 : H2 - 1] = T::load_global(xf + TILE);
                 }
             }
         }
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                         b1 = T::load_lds(xs, ld, 16 + (lane & 15), ks - c0, lane);
                     } else {
                         b0 = bt[STAGE ? 0 : u][0];
-                        if (H2 == 2) b1 = bt[STAGE ? 0 : u][H2 - 1];
+                        if (H2 == 2) b1 = bt[STAGE ? 0 : u][STAGE ? 0 : H2 - 1];
                     }
 #pragma unroll
                     for (int i = 0; i < NB; ++i) {
