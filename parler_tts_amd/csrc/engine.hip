@@ -1215,6 +1215,8 @@ int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* 
         HIP_TRY(rows_to_frag_launch(X, xf, M, K, dtype, s));
         g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = xf;
     }
+    const bool force_halves = prologue == 6;   // 6 = 4 on the half-split workgroup (diagnostics)
+    if (force_halves) prologue = 4;
     if (prologue == 4) {   // LayerNorm through the folded path: gamma into the weights, raw rows as fragments
         const size_t mrows = (size_t)(M + 31) / 32 * 32;
         HIP_TRY(hipMalloc(&wf, (size_t)Np * K * esz));
@@ -1225,10 +1227,48 @@ int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* 
         HIP_TRY(fold_layernorm_launch(wp, wf, gamma, beta, c1, c2, Np, K, dtype, s));
         HIP_TRY(rows_to_frag_launch(X, xf, M, K, dtype, s));
         g.W = wf; g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = xf; g.fold = 1; g.c1 = c1; g.c2 = c2;
+        g.force_halves = force_halves ? 1 : 0;
     }
     int v = gemm_validate(g, dtype);
     hipError_t he = hipSuccess;
     if (v == 0) he = gemm_launch(g, dtype, s);
+    // hammer mode (PTTS_TEST_GEMM_ITERS=n): relaunch the same GEMM n times and compare every result bitwise with the
+    // first on the device - the repeatability probe for timing-dependent code-generation hazards (run it while another
+    // process keeps the GPU busy)
+    if (v == 0 && he == hipSuccess && getenv("PTTS_TEST_GEMM_ITERS")) {
+        const int iters = atoi(getenv("PTTS_TEST_GEMM_ITERS"));
+        const size_t n = (size_t)M * N;
+        float *yref = nullptr, *y2 = nullptr;
+        unsigned *cnt = nullptr, hcnt[2] = {0, 0};
+        if (hipMalloc((void**)&yref, n * 4) == hipSuccess && hipMalloc((void**)&y2, n * 4) == hipSuccess &&
+            hipMalloc((void**)&cnt, 8) == hipSuccess) {
+            (void)hipMemcpyAsync(yref, Y, n * 4, hipMemcpyDeviceToDevice, s);
+            int bad_launches = 0, first_iter = -1;
+            unsigned first_idx = 0, total = 0;
+            GemmArgs g2 = g;
+            g2.out = y2;
+            for (int it = 0; it < iters; ++it) {
+                (void)hipMemsetAsync(cnt, 0, 8, s);
+                (void)gemm_launch(g2, dtype, s);
+                (void)compare_launch(y2, yref, n, cnt, cnt + 1, s);
+                (void)hipMemcpyAsync(hcnt, cnt, 8, hipMemcpyDeviceToHost, s);
+                (void)hipStreamSynchronize(s);
+                if (hcnt[0]) {
+                    if (bad_launches < 8)
+                        fprintf(stderr, "hammer: launch %d: %u elements differ, one at row %u col %u\n", it, hcnt[0],
+                                (unsigned)(hcnt[1] / N), (unsigned)(hcnt[1] % N));
+                    if (!bad_launches) { first_iter = it; first_idx = hcnt[1]; }
+                    ++bad_launches;
+                    total += hcnt[0];
+                }
+            }
+            fprintf(stderr, "hammer: %d launches, %d differ from the first (%u elements; first at launch %d index %u)\n", iters,
+                    bad_launches, total, first_iter, first_idx);
+        }
+        if (yref) (void)hipFree(yref);
+        if (y2) (void)hipFree(y2);
+        if (cnt) (void)hipFree(cnt);
+    }
     hipError_t se = hipStreamSynchronize(s);
     (void)hipFree(wp);
     if (wf) (void)hipFree(wf);

@@ -22,6 +22,7 @@ struct GemmArgs {
     // folded LayerNorm (PRO_FRAG only): `xfrag` holds the RAW residual rows, W is diag(gamma).W, and the
     // normalisation is applied after the MFMA: y = rstd * (x.W' - mean * c1) + c2   (see fold_layernorm_launch)
     int fold = 0;
+    int force_halves = 0;         // test hook only: run the folded GEMM on the half-split workgroup
     const float* c1 = nullptr;    // [N] sum_k W'[n][k]
     const float* c2 = nullptr;    // [N] sum_k beta[k] * W[n][k]
     // epilogue
@@ -66,4 +67,6 @@ hipError_t rows_to_frag_launch(const float* X, void* xfrag, int M, int K, int dt
 // look-ahead weights (packed [N][2K]): columns 0..K-1 = Wf (the gamma-folded projection, packed [N][K]); columns K..2K-1 =
 // Wf . Wo, Wo packed [K][K] = the residual projection whose output the folded projection would have read
 hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int N, int K, int dtype, hipStream_t stream);
+// number of elements of `a` that differ bitwise from `b`; *first = linear index of one of them (diagnostics)
+hipError_t compare_launch(const float* a, const float* b, size_t n, unsigned* count, unsigned* first, hipStream_t stream);
 hipError_t convert_launch(const float* src, void* dst, size_t n, int dtype, hipStream_t stream);

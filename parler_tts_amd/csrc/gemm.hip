@@ -519,6 +519,11 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     // few feature blocks and more than 16 live rows: one 16-row half per workgroup doubles the busy CUs
     // (with a second role the half-split grid is used for every M: the arithmetic must not depend on the batch size)
     const bool halves = a.N <= 2048 && (a.M > 16 || a.W2) && a.epi != EPI_GATED_FRAG;
+    if (a.fold && a.force_halves && halves) {     // diagnostics only (ptts_test_gemm prologue 6)
+        if (nw == 16) return launch_one<P, 16, 1, false, 1, 1, true>(a, stream);
+        if (nw == 8) return launch_one<P, 8, 1, false, 1, 1, true>(a, stream);
+        return launch_one<P, 4, 1, false, 1, 1, true>(a, stream);
+    }
     if (a.fold) {
         // always the two-half workgroup: the half-split folded instance (cross-q) was the one configuration that
         // stayed non-repeatable when two processes shared the GPU (about 1 launch in 3e4),
@@ -614,6 +619,14 @@ __global__ __launch_bounds__(256) void lookahead_build_kernel(const typename P::
     out[wpack_off<P>(n, jj, 2 * K)] = to_elem<P>(acc);
 }
 
+__global__ void compare_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, unsigned* count, unsigned* first) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (__builtin_bit_cast(unsigned, a[i]) != __builtin_bit_cast(unsigned, b[i])) {
+        if (atomicAdd(count, 1u) == 0) *first = (unsigned)i;
+    }
+}
+
 template <typename P>
 __global__ void rows_to_frag_kernel(const float* __restrict__ X, typename P::elem_t* xf, int M, int K) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -695,6 +708,11 @@ hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int
     else
         hipLaunchKernelGGL(lookahead_build_kernel<PF32>, grid, dim3(256), 0, stream, (const float*)Wf, (const float*)Wo,
                            (float*)out, N, K);
+    return hipGetLastError();
+}
+
+hipError_t compare_launch(const float* a, const float* b, size_t n, unsigned* count, unsigned* first, hipStream_t stream) {
+    hipLaunchKernelGGL(compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, n, count, first);
     return hipGetLastError();
 }
 
