@@ -419,7 +419,8 @@ int run_select_half(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
     sa.pad = c.pad_token_id; sa.eos = c.eos_token_id; sa.do_sample = sp.do_sample; sa.top_k = sp.top_k;
     sa.temperature = sp.temperature; sa.guidance = sp.guidance_scale; sa.seed = sp.seed;
     sa.top_p = (sp.top_p > 0.f && sp.top_p < 1.f) ? sp.top_p : 1.0f;
-    HIP_TRY(select_launch(sa, s));   // the last row to finish also advances pos / cur_len / step_count
+    HIP_TRY(select_launch(sa, s));
+    HIP_TRY(advance_launch(e->state, e->unfinished, sa.rows, e->L, s));   // pos / cur_len / step_count / unfinished count
     return PTTS_OK;
 }
 

@@ -38,7 +38,7 @@ hipError_t embed_codebooks_launch(const EmbedArgs& a, int B, int dtype, hipStrea
 hipError_t embed_prompt_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s);
 hipError_t advance_prompt_launch(StepState* st, hipStream_t s);
 hipError_t select_launch(const SelectArgs& a, hipStream_t s);
-hipError_t advance_launch(StepState* st, int* unf_count, int L, hipStream_t s);
+hipError_t advance_launch(StepState* st, const int* unfinished, int rows, int L, hipStream_t s);
 hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,
                               int L, int col, hipStream_t s);
 hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s);

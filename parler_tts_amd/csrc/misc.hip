@@ -260,37 +260,33 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         a.raw_ids[(size_t)row * a.L + cur] = nxt;
         const int unf_new = unf && (nxt != (long long)a.eos);
         a.unfinished[row] = unf_new;
-        if (unf_new) atomicAdd(a.unf_count, 1);
         const long long forced = a.pattern[(size_t)row * a.L + cur];
         const int feed = (int)(forced == -1 ? nxt : forced);
         a.tok_in[row] = feed;
         if (a.guidance > 1.0f) a.tok_in[row + a.rows] = feed;   // both halves see the same ids (M:2112)
-        // the last row to finish advances the loop state (every row has read cur_len/step_count by then)
-        __threadfence();
-        const int ticket = atomicAdd(a.unf_count + 1, 1);
-        if (ticket == a.rows - 1) {
-            __threadfence();
-            StepState* s = a.state;
-            const int unf_total = atomicAdd(a.unf_count, 0);
-            s->pos += 1;
-            s->cur_len += 1;
-            s->step_count += 1;
-            s->n_unfinished = unf_total;
-            if (unf_total == 0 && s->done_len == 0) s->done_len = s->cur_len;
-            a.unf_count[0] = 0;
-            a.unf_count[1] = 0;
-        }
+        // the loop state is advanced by advance_kernel, launched right behind this one: a "last block advances" ticket
+        // here cost 2 x rows serialised device-scope atomics per step (~8 of this kernel's 13 us at 288 rows)
     }
 }
 
-__global__ void advance_kernel(StepState* s, int* unf_count, int L) {
+// one workgroup: counts the rows still unfinished after the selection and advances the loop state
+// (unfinished_sequences.max() == 0 / MaxLengthCriteria of the third-party loop)
+__global__ __launch_bounds__(256) void advance_kernel(StepState* s, const int* unfinished, int rows, int L) {
+    __shared__ int part[4];
     if (s->cur_len >= L) return;
-    s->pos += 1;
-    s->cur_len += 1;
-    s->step_count += 1;
-    s->n_unfinished = *unf_count;
-    if (*unf_count == 0 && s->done_len == 0) s->done_len = s->cur_len;
-    *unf_count = 0;
+    int n = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) n += unfinished[r] ? 1 : 0;
+    n = (int)wave_sum((float)n);              // rows <= 2^24: exact in fp32
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int unf_total = part[0] + part[1] + part[2] + part[3];
+        s->pos += 1;
+        s->cur_len += 1;
+        s->step_count += 1;
+        s->n_unfinished = unf_total;
+        if (unf_total == 0 && s->done_len == 0) s->done_len = s->cur_len;
+    }
 }
 
 // feed tokens for the first decode step: the masked last column of the start ids (M:2107, M:2120-2130)
@@ -365,8 +361,8 @@ hipError_t select_launch(const SelectArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(select_kernel, dim3(a.rows), dim3(256), (size_t)2 * a.V * sizeof(float), s, a);
     return hipGetLastError();
 }
-hipError_t advance_launch(StepState* st, int* unf_count, int L, hipStream_t s) {
-    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, st, unf_count, L);
+hipError_t advance_launch(StepState* st, const int* unfinished, int rows, int L, hipStream_t s) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(256), 0, s, st, unfinished, rows, L);
     return hipGetLastError();
 }
 hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,
