@@ -123,7 +123,7 @@ struct ptts_engine {
     float *self_bias = nullptr, *cross_bias = nullptr;
     int s_cap = 0;
     bool has_self_bias = false;
-    int *tok_in = nullptr, *unfinished = nullptr, *unf_count = nullptr;
+    int *tok_in = nullptr, *unfinished = nullptr;
     long long* force = nullptr;
     bool use_force = false;
     StepState* state = nullptr;
@@ -414,7 +414,7 @@ int run_select_half(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
     const ptts_config& c = e->cfg;
     SelectArgs sa;
     sa.logits = e->logits; sa.rows = e->B * c.codebooks; sa.V = e->Vp; sa.vocab = c.vocab; sa.L = e->L; sa.state = e->state;
-    sa.raw_ids = e->raw_ids; sa.pattern = e->pattern; sa.unfinished = e->unfinished; sa.unf_count = e->unf_count;
+    sa.raw_ids = e->raw_ids; sa.pattern = e->pattern; sa.unfinished = e->unfinished;
     sa.tok_in = e->tok_in; sa.force = e->use_force ? e->force : nullptr; sa.probs = e->probs;
     sa.pad = c.pad_token_id; sa.eos = c.eos_token_id; sa.do_sample = sp.do_sample; sa.top_k = sp.top_k;
     sa.temperature = sp.temperature; sa.guidance = sp.guidance_scale; sa.seed = sp.seed;
@@ -668,7 +668,6 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->enc_h, sizeof(float) * ((size_t)Bm * cfg->max_desc_len + 32) * D);
     A(e->tok_in, sizeof(int) * rows * K);
     A(e->unfinished, sizeof(int) * rows * K);
-    A(e->unf_count, sizeof(int) * 4);
     A(e->force, sizeof(long long) * rows * K);
     A(e->state, sizeof(StepState));
     if (cfg->t5_layers > 0) {
@@ -689,7 +688,6 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     for (size_t i = 0; i < tab.size(); ++i) tab[i] = (int)i;
     if (he == hipSuccess) he = hipMemcpy(e->cross_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemset(e->state, 0, sizeof(StepState));
-    if (he == hipSuccess) he = hipMemset(e->unf_count, 0, 4 * sizeof(int));
     if (he == hipSuccess) he = hipMemset(e->attn_frag, 0, e->esz * rows * D);
     if (he == hipSuccess) he = hipMemset(e->x_frag, 0, e->esz * rows * D);
     if (he == hipSuccess) he = hipMemset(e->x_frag2, 0, e->esz * rows * D);
@@ -930,7 +928,6 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     HIP_TRY(hipStreamSynchronize(s));  // `st` lives on this stack frame
     std::vector<int> ones(B * c.codebooks, 1);
     HIP_TRY(hipMemcpyAsync(e->unfinished, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(e->unf_count, 0, 4 * sizeof(int), s));
     HIP_TRY(hipStreamSynchronize(s));
     // the P prompt positions, one cached position at a time (causal attention == incremental decode)
     for (int p = 0; p < P; ++p) {

@@ -24,7 +24,6 @@ struct SelectArgs {
     long long* raw_ids = nullptr;        // [rows][L]
     const long long* pattern = nullptr;  // [rows][L]
     int* unfinished = nullptr;           // [rows]
-    int* unf_count = nullptr;
     int* tok_in = nullptr;               // [rows (x2)]
     const long long* force = nullptr;    // [rows] or null
     float* probs = nullptr;              // [rows][V] or null
