@@ -312,6 +312,7 @@ def generate_ids(
     forced_tokens: Optional[Dict[int, torch.Tensor]] = None,
     step_times: Optional[list] = None,
     logits_processor: Optional[list] = None,
+    decoder_input_ids: Optional[torch.Tensor] = None,
 ) -> Dict[str, torch.Tensor]:
     """The hot loop: M:2530-2537 (delay mask) + prepare_inputs_for_generation M:2081-2148 +
     forward M:1927-2079 + the third-party greedy/sample step.
@@ -343,8 +344,10 @@ def generate_ids(
             pmask = pmask.repeat(2, 1)
     enc_h = encoder_glue(cfg, sd, enc, amask)  # constant across steps
 
-    ids = torch.full((B * K, 1), cfg.decoder_start_token_id if cfg.decoder_start_token_id is not None else bos,
-                     dtype=torch.long)                                           # M:2174-2181
+    start_tok = cfg.decoder_start_token_id if cfg.decoder_start_token_id is not None else bos
+    ids = torch.full((B * K, 1), start_tok, dtype=torch.long)                    # M:2174-2181
+    if decoder_input_ids is not None:                                            # M:2163-2185: user prefix, start column ensured
+        ids = decoder_input_ids if not bool((decoder_input_ids[..., 0] != start_tok).all()) else torch.cat([ids, decoder_input_ids], -1)
     ids, pattern = build_delay_pattern_mask(ids, bos, pad, max_length, K)       # M:2530-2535
     cache = KVCache(kv_mode, max_len=(0 if prompt_h is None else prompt_h.shape[1]) + max_length)
     unfinished = torch.ones(B * K, dtype=torch.long)

@@ -940,7 +940,18 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
         if (e->dbg_stop >= 0 && e->dbg_count >= e->dbg_stop) break;
         HIP_TRY(advance_prompt_launch(e->state, s));
     }
-    e->host_pos = P;
+    // decoder prefix (user `decoder_input_ids` longer than the start column, M:2150-2195): its columns 0 .. start_len-2 go
+    // through the cache like prompt positions; the delay-pattern mask holds every prefix value (M:108-111), so the
+    // masked column IS the model input, and nothing is sampled or latched for these columns
+    for (int j = 0; j + 1 < start_len; ++j) {
+        HIP_TRY(init_tokens_launch(e->raw_ids, e->pattern, e->tok_in, B * c.codebooks, B_eff * c.codebooks, L, j, s));
+        e->xf_cur = e->x_frag;
+        HIP_TRY(embed_codebooks_launch(embed_args(e), B_eff, e->dt, s));
+        e->host_pos = P + j;
+        PTTS_TRY(run_layers(e, s, false));
+        HIP_TRY(advance_prompt_launch(e->state, s));
+    }
+    e->host_pos = P + start_len - 1;
     e->host_cur = start_len;
     HIP_TRY(init_tokens_launch(e->raw_ids, e->pattern, e->tok_in, B * c.codebooks, B_eff * c.codebooks, L, start_len - 1, s));
     e->use_force = false;

@@ -402,11 +402,11 @@ class ParlerTTSForConditionalGeneration:
         logits_processor = list(logits_processor) if logits_processor else []
         stopping_criteria = list(stopping_criteria) if stopping_criteria else []
         allowed = {"input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "encoder_outputs",
-                   "prompt_hidden_states", "return_raw_ids"}
-        unsupported = {"decoder_input_ids", "input_values", "decoder_attention_mask"}
+                   "prompt_hidden_states", "decoder_input_ids", "return_raw_ids"}
+        unsupported = {"input_values", "decoder_attention_mask"}
         for k in model_kwargs:
             if k in unsupported:
-                raise NotImplementedError(f"`{k}` (audio prompts / decoder prefixes) is a SURVEY 8(f) 'next' row")
+                raise NotImplementedError(f"`{k}` (audio prompts) is a SURVEY 8(f) 'next' row")
             if k not in allowed:
                 raise ValueError(f"The following `model_kwargs` are not used by the model: ['{k}']")
         if gen.pad_token_id is None and gen.eos_token_id is not None:   # M:2432-2442
@@ -444,6 +444,12 @@ class ParlerTTSForConditionalGeneration:
         # 5./6. start ids and max_length (M:2490-2527)
         start_tok = gen.decoder_start_token_id if gen.decoder_start_token_id is not None else gen.bos_token_id
         ids = torch.full((B * K, 1), start_tok, dtype=torch.long, device=dev)
+        dec_in = model_kwargs.get("decoder_input_ids")
+        if dec_in is not None:       # user prefix [B*K, s]; the start column is prepended when it is missing (M:2184-2185)
+            dec_in = dec_in.to(dev, torch.long)
+            if dec_in.dim() != 2 or dec_in.shape[0] != B * K:
+                raise ValueError(f"decoder_input_ids must be [batch * num_codebooks = {B * K}, prefix_len], got {tuple(dec_in.shape)}")
+            ids = dec_in if not bool((dec_in[..., 0] != start_tok).all()) else torch.cat([ids, dec_in], dim=-1)
         if gen.max_new_tokens is not None:
             gen.max_length = gen.max_new_tokens + ids.shape[-1]
         if gen.min_length is not None and gen.min_length > gen.max_length:

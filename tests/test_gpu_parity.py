@@ -856,3 +856,35 @@ def test_lookahead_cross_q_agrees_with_separate_projection(hip):
     a = _fresh_engine_logits("tiny_greedy", "fp32", {"PTTS_LOOKAHEAD": "1", "PTTS_LN_FOLD": "1"})
     b = _fresh_engine_logits("tiny_greedy", "fp32", {"PTTS_LOOKAHEAD": "0", "PTTS_LN_FOLD": "1"})
     assert (a - b).abs().max().item() < 1e-4
+
+
+def test_decoder_input_ids_prefix(hip):
+    """User `decoder_input_ids` (M:2150-2195): the prefix is delay-shifted by build_delay_pattern_mask (M:108-111), passes
+    through the cache teacher-forced, and generation continues after it.  fp32 engine vs the oracle loop, bit-exact."""
+    from oracle import cpu_ref
+
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, "fp32")
+    _, sd = state_dict_for("tiny_greedy", meta, parts=("text_encoder", "decoder", "audio_encoder"))
+    desc, amask, prompt, pmask = case_inputs(f)
+    K = cfg.decoder.num_codebooks
+    B = desc.shape[0]
+    L = int(f["max_length"])
+    enc = torch.from_numpy(f["enc_t5"])
+    g = torch.Generator().manual_seed(11)
+    prefix = torch.randint(0, cfg.decoder.pad_token_id, (B * K, 5), generator=g)      # plain codec ids
+    kw = dict(encoder_outputs=(enc,), attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L,
+              return_raw_ids=True)
+    got = model.generate(decoder_input_ids=prefix, **kw)
+    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, decoder_input_ids=prefix)
+    assert torch.equal(model.last_raw_ids.cpu()[:, 6:], ref["raw_ids"][:, 6:])          # sampled columns (prefix = 1 + 5)
+    want = cpu_ref.undelay(cfg, ref["raw_ids"], ref["pattern"])
+    assert torch.equal(got.cpu(), want)
+    # a prefix that already starts with the start token is taken as is
+    with_start = torch.cat([torch.full((B * K, 1), cfg.decoder.bos_token_id), prefix], dim=-1)
+    again = model.generate(decoder_input_ids=with_start, **kw)
+    assert torch.equal(again, got)
+    base = model.generate(**kw)
+    assert not torch.equal(base, got)
+    with pytest.raises(ValueError):
+        model.generate(decoder_input_ids=prefix[:-1], **kw)
