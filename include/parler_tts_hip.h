@@ -107,8 +107,9 @@ int ptts_set_prompt_embeds(ptts_engine* e, const float* embeds);
  *        prompt_ids   [B_eff][P] int64 (P may be 0)    prompt_mask [B_eff][P] int32 or NULL
  *        pattern      [B*K][L] int64 delay pattern (build_delay_pattern_mask, M:77-139)
  *        raw_ids      [B*K][L] int64 caller-owned output; column 0.. are filled by decode steps
- *      After it, StepState = {pos = P, cur_len = first free column}. ---- * start_len > 1 = a decoder prefix (user decoder_input_ids, modeling_parler_tts.py:2150-2195): columns 0..start_len-2 of
- * raw_ids (as masked by `pattern`) pass through the cache like prompt positions; sampling starts at column start_len. */
+ *      start_len > 1 = a decoder prefix (user decoder_input_ids, modeling_parler_tts.py:2150-2195): columns
+ *      0..start_len-2 of raw_ids (as masked by `pattern`) pass through the cache like prompt positions.
+ *      After it, StepState = {pos = P + start_len - 1, cur_len = start_len = first free column}. ---- */
 int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P, int32_t L,
                  const float* enc_states, const int32_t* attention_mask, const int64_t* prompt_ids,
                  const int32_t* prompt_mask, const int64_t* pattern, int64_t* raw_ids, int32_t start_len,
