@@ -5,7 +5,9 @@
 // workgroup streams S x 64 K values and S x 64 V values exactly once.
 //   * K/V rows are 64 elements (128 B bf16 / 256 B fp32).  A wave64 `global_load_dwordx4` covers
 //     TPW = 8 (bf16) / 4 (fp32) consecutive tokens = 1 KiB contiguous inside a 64-token page;
-//     UNR such loads are issued back-to-back per wave before the first use.
+//     UNR such loads are issued back-to-back per wave before the first use.  The loads are
+//     non-temporal (the cache is read once per step) and the pool keeps one slab per (layer, K/V, head),
+//     so a workgroup with consecutive page ids streams one contiguous region.
 //   * pass 1: scores s_t = q.k_t (+ additive mask, 0 or finfo.min as the reference adds it, M:339)
 //     -> LDS; lanes of a token reduce with wave shuffles
 //   * softmax over the whole row in fp32 exactly as torch does it (max, exp, sum, divide; M:342)
@@ -13,6 +15,9 @@
 //   * output is written in MFMA B-fragment order for the out_proj GEMM (gemm.hip PRO_FRAG)
 // The number of cached tokens comes from device memory (StepState.pos) so that one captured
 // hipGraph serves every step.
+// attn_page_kernel: contexts of <= 64 keys (cross-attention over a short description): one wave per
+// (utterance, head), no LDS, no barrier; it also finishes the look-ahead query projection (LayerNorm
+// correction from per-block row statistics).
 #include "ptts_common.h"
 #include "attn.h"
 #include <cstdlib>

@@ -15,6 +15,13 @@
 //     producing kernel already wrote in B-operand order (attention output, GELU output).
 //   * K-split partial sums meet in LDS and are added in fixed wave order (deterministic), then the
 //     epilogue runs fused: residual add, q scaling, KV-cache append, GELU -> fragments, T5 gating, ...
+//   * decoder LayerNorms are FOLDED behind the MFMA (bf16 mode): the fragments are the raw residual rows,
+//     W carries gamma, the row statistics come from the fragments on the VALU, and the epilogue applies
+//     rstd * (acc - mean * c1) + c2  (fold_ln_kernel builds W', c1, c2 once per weight set)
+//   * the residual out-projection of the self-attention can carry a second ROLE in the same launch: extra
+//     workgroups compute the look-ahead cross-attention query  [x | a] . [Wq' ; Wq'.Wo]^T  
+//   * code-generation rules learnt the hard way: tile guards must be scalar (MFMA ignores
+//     EXEC), >64-bit LDS stores are issued with their drain, operands of queued MFMAs keep their own registers
 //
 // Reference arithmetic: nn.Linear (bias-free) M:256-259, LayerNorm M:402-413/446/467/487/959,
 // q scaling M:282, KV append M:299-304, GELU MLP M:488-490, LM heads M:1143, enc_to_dec_proj M:2010-2017,
