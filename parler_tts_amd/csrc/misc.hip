@@ -115,6 +115,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     __shared__ float wv[4];
     __shared__ int wi[4];
     __shared__ unsigned hist[256];
+    __shared__ unsigned scan[256];
+    __shared__ float fscan[256];
     __shared__ unsigned sel_prefix, sel_remaining;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int V = a.vocab;          // valid ids; rows are a.V (= padded stride) apart
@@ -164,11 +166,23 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    unsigned rem = sel_remaining, acc = 0; int bin = 255;
-                    for (; bin > 0; --bin) { if (acc + hist[bin] >= rem) break; acc += hist[bin]; }
-                    sel_prefix = prefix | ((unsigned)bin << shift);
-                    sel_remaining = rem - acc;
+                // the bin that holds the rem-th largest key: suffix counts S[b] = sum_{b' >= b} hist[b'] by a
+                // Hillis-Steele scan over the 256 bins (one per thread), then the unique b with S[b] >= rem > S[b+1]
+                // (a serial walk by one thread cost ~10 us per pass: 256 dependent LDS reads)
+                const unsigned rem = sel_remaining;
+                unsigned sfx = hist[tid];
+                for (int off = 1; off < 256; off <<= 1) {
+                    scan[tid] = sfx;
+                    __syncthreads();
+                    if (tid + off < 256) sfx += scan[tid + off];
+                    __syncthreads();
+                }
+                scan[tid] = sfx;
+                __syncthreads();
+                const unsigned above = tid < 255 ? scan[tid + 1] : 0u;     // keys in strictly higher bins
+                if ((sfx >= rem && above < rem) || (tid == 0 && sfx < rem)) {   // (tid 0 fallback: fewer keys than rem)
+                    sel_prefix = prefix | ((unsigned)tid << shift);
+                    sel_remaining = rem - (sfx >= rem ? above : 0u);
                 }
                 __syncthreads();
             }
@@ -238,15 +252,38 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             }
             __syncthreads();
         }
-        // ---- inverse CDF, index order (one thread: V ~ 1e3) ----
-        if (tid == 0) {
-            float u = philox_uniform(a.seed, (uint32_t)row, (uint32_t)a.state->step_count);
-            float c = 0.f; int pick = -1, last = 0;
-            for (int v = 0; v < V; ++v) {
-                float p = sv[v];
-                if (p > 0.f) { last = v; c += p; if (pick < 0 && c > u) pick = v; }
+        // ---- inverse CDF in index order: thread t owns the contiguous block [t*CH, (t+1)*CH); block sums are prefix-
+        //      scanned over the 256 threads, then each thread walks its own block for the first crossing of u.
+        //      (One thread walking all V entries cost tens of microseconds; the summation order differs from a plain
+        //      left-to-right cumsum only in the last bits, which moves a draw only when u sits within ~1e-7 of an edge.)
+        {
+            const float u = philox_uniform(a.seed, (uint32_t)row, (uint32_t)a.state->step_count);
+            const int CH = (V + 255) / 256;
+            const int v0 = tid * CH, v1 = min(V, v0 + CH);
+            float bsum = 0.f;
+            int blast = -1;
+            for (int v = v0; v < v1; ++v) { const float p = sv[v]; if (p > 0.f) { bsum += p; blast = v; } }
+            float inc = bsum;                       // inclusive scan of the block sums
+            for (int off = 1; off < 256; off <<= 1) {
+                fscan[tid] = inc;
+                __syncthreads();
+                if (tid >= off) inc += fscan[tid - off];
+                __syncthreads();
             }
-            wi[0] = pick < 0 ? last : pick;
+            int pick = 0x7fffffff;
+            float c = inc - bsum;                   // mass before this block
+            for (int v = v0; v < v1; ++v) { const float p = sv[v]; if (p > 0.f) { c += p; if (pick == 0x7fffffff && c > u) pick = v; } }
+            // first crossing over all blocks = smallest index; fallback = last index with non-zero probability
+            int lastnz = blast;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { pick = min(pick, __shfl_xor(pick, o)); lastnz = max(lastnz, __shfl_xor(lastnz, o)); }
+            __shared__ int wlast[4];
+            if (lane == 0) { wi[w] = pick; wlast[w] = lastnz; }
+            __syncthreads();
+            pick = min(min(wi[0], wi[1]), min(wi[2], wi[3]));
+            lastnz = max(max(wlast[0], wlast[1]), max(wlast[2], wlast[3]));
+            __syncthreads();
+            if (tid == 0) wi[0] = pick == 0x7fffffff ? lastnz : pick;
         }
         __syncthreads();
         choice = wi[0];
