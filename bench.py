@@ -212,6 +212,12 @@ def main():
             "decode_loop_tokens_per_s": round(tokens / world / max(phase["decode_ms"] / 1e3, 1e-9), 1) if phase["decode_ms"] else None,
             "phase_ms_per_step_rank0": {k: round(v / args.steps, 2) for k, v in phase.items()},
             "passes_bit_identical_rank0": repeatable,
+            # codec decode (MFMA-bound one-off phase): ~1.61 GFLOP per frame per utterance; every product runs as
+            # three fp16 MFMA products (hi.hi + hi.lo + lo.hi), so the matrix cores do 3x this rate against the fp16 peak
+            "dac_decode_rank0": None if args.no_dac or not phase["post_ms"] else {
+                "tflops_fp32_equivalent": round(1.61e9 * B * F / (phase["post_ms"] / args.steps / 1e3) / 1e12, 1),
+                "mfma_fp16_tflops": round(3 * 1.61e9 * B * F / (phase["post_ms"] / args.steps / 1e3) / 1e12, 1),
+                "frac_of_fp16_dense_peak_2500": round(3 * 1.61e9 * B * F / (phase["post_ms"] / args.steps / 1e3) / 1e12 / 2500.0, 3)},
             "roofline": {
                 "kernel": "attn_decode_kernel (self-attention over the paged KV cache)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
