@@ -888,3 +888,59 @@ def test_decoder_input_ids_prefix(hip):
     assert not torch.equal(base, got)
     with pytest.raises(ValueError):
         model.generate(decoder_input_ids=prefix[:-1], **kw)
+
+
+def test_lookahead_cross_q_two_m_tiles_bf16(hip):
+    """Look-ahead cross-q with more than one 32-row m-tile (batch 40; the same layout guidance gives at batch 32):
+    teacher-forced logits of the mini_v0.1 decoder, look-ahead on vs off."""
+    from parler_tts_amd import _hip
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.delay_pattern import build_delay_pattern_mask
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    cfg.decoder.num_hidden_layers = 4            # same widths, fewer layers
+    sd = synthetic_state_dict(cfg, seed=0, never_eos=True, parts=("text_encoder", "decoder"))
+    B, T, P, steps = 40, 12, 6, 6
+    L = steps + 2
+    K = cfg.decoder.num_codebooks
+    g = torch.Generator().manual_seed(7)
+    desc = torch.randint(2, 32100, (B, T), generator=g)
+    prompt = torch.randint(2, 32100, (B, P), generator=g)
+    forced = torch.randint(0, 1024, (steps, B * K), generator=g)
+    _models.clear()
+    torch.cuda.empty_cache()
+
+    def run(flag):
+        old = os.environ.get("PTTS_LOOKAHEAD")
+        os.environ["PTTS_LOOKAHEAD"] = flag
+        try:
+            m = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device="cuda:0")
+            eng = m.engine(B, T, P, L)
+            enc = eng.t5_encode(desc.cuda(), torch.ones(B, T, dtype=torch.long, device="cuda"))
+            ids = torch.full((B * K, 1), cfg.decoder.bos_token_id, dtype=torch.long)
+            ids, pattern = build_delay_pattern_mask(ids, cfg.decoder.bos_token_id, cfg.decoder.pad_token_id, L, K)
+            pattern = pattern.cuda().contiguous()
+            raw = torch.full((B * K, L), cfg.decoder.pad_token_id, dtype=torch.long, device="cuda")
+            raw[:, :1] = ids.cuda()
+            eng.prefill(B, B, enc.contiguous(), torch.ones(B, T, dtype=torch.int32, device="cuda"), prompt.cuda().contiguous(),
+                        None, pattern, raw, 1)
+            sp = _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
+            out = []
+            for i in range(steps):
+                eng.set_forced_tokens(forced[i])
+                eng.decode_steps(1, sp)
+                out.append(eng.last_logits(B * K).cpu())
+            eng.set_forced_tokens(None)
+            return torch.stack(out)
+        finally:
+            if old is None:
+                os.environ.pop("PTTS_LOOKAHEAD", None)
+            else:
+                os.environ["PTTS_LOOKAHEAD"] = old
+
+    a, b = run("1"), run("0")
+    assert not torch.isnan(a).any()
+    assert (a - b).abs().max().item() < 0.05
+    assert (a.argmax(-1) == b.argmax(-1)).float().mean().item() > 0.97

@@ -16,7 +16,8 @@ from parler_tts_amd.weights import synthetic_state_dict
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 cfg = mini_v01_config()
 sd = synthetic_state_dict(cfg, seed=0, never_eos=True, parts=("text_encoder", "decoder"))
-B, T, P, L = 32, 40, 16, steps + 2
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+T, P, L = 40, 16, steps + 2
 K = cfg.decoder.num_codebooks
 g = torch.Generator().manual_seed(7)
 desc = torch.randint(2, 32100, (B, T), generator=g)
