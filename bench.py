@@ -32,6 +32,20 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def decode_loop_roofline(dec, B, T, P, n_steps, esz, seconds):
+    """Whole decode loop against the HBM roofline of SURVEY.md 8(d).  Algorithmic bytes: per step the decoder weights
+    (L * (4D^2 + 2D^2 + 2DF + 6D) + 2D + K*V*D elements) and the cross K/V once, plus the self K/V of every cached
+    position (P prompt positions + the tokens so far): 12.79 TB for mini_v0.1 bf16, B=32, P=16, T=40, 2579 steps."""
+    D, Lr, F = dec.hidden_size, dec.num_hidden_layers, dec.ffn_dim
+    w_el = Lr * (6 * D * D + 2 * D * F + 6 * D) + 2 * D + dec.num_codebooks * dec.vocab_size * D
+    per_step = w_el * esz + Lr * 2 * B * T * D * esz
+    kv_self = Lr * 2 * B * D * esz * (n_steps * P + n_steps * (n_steps + 1) / 2)
+    total = n_steps * per_step + kv_self
+    gbs = total / 1e9 / max(seconds, 1e-9)
+    return {"algorithmic_TB": round(total / 1e12, 3), "time_s": round(seconds, 4), "achieved_GBs": round(gbs, 1),
+            "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
 def synth_inputs(cfg, B, T, P, seed):
     g = torch.Generator().manual_seed(seed)
     desc = torch.randint(2, min(32100, cfg.text_encoder.vocab_size), (B, T), generator=g)
@@ -212,6 +226,8 @@ def main():
             "decode_loop_tokens_per_s": round(tokens / world / max(phase["decode_ms"] / 1e3, 1e-9), 1) if phase["decode_ms"] else None,
             "phase_ms_per_step_rank0": {k: round(v / args.steps, 2) for k, v in phase.items()},
             "passes_bit_identical_rank0": repeatable,
+            "decode_loop_roofline_rank0": decode_loop_roofline(cfg.decoder, B, T, P, n_steps, 2 if args.dtype == "bf16" else 4,
+                                                               phase["decode_ms"] / args.steps / 1e3) if phase["decode_ms"] else None,
             # codec decode (MFMA-bound one-off phase): ~1.61 GFLOP per frame per utterance; every product runs as
             # three fp16 MFMA products (hi.hi + hi.lo + lo.hi), so the matrix cores do 3x this rate against the fp16 peak
             "dac_decode_rank0": None if args.no_dac or not phase["post_ms"] else {
