@@ -18,7 +18,8 @@ g = torch.Generator().manual_seed(1234)
 desc = torch.randint(2, 32100, (32, 40), generator=g)
 prompt = torch.randint(2, 32100, (32, 16), generator=g)
 for name, kw in (("greedy", dict(do_sample=False)), ("sample top_k=50 T=0.7", dict(do_sample=True, top_k=50, temperature=0.7)),
-                 ("sample top_k=50 top_p=0.9", dict(do_sample=True, top_k=50, top_p=0.9, temperature=1.0))):
+                 ("sample top_k=50 top_p=0.9", dict(do_sample=True, top_k=50, top_p=0.9, temperature=1.0)),
+                 ("greedy + guidance_scale 3 (64 rows)", dict(do_sample=False, guidance_scale=3.0))):
     for rep in range(2):
         m.phase_times = {"t5_prefill_ms": 0.0, "decode_ms": 0.0, "post_ms": 0.0}
         m.generate(input_ids=desc, prompt_input_ids=prompt, max_length=L, return_raw_ids=True, **kw)
