@@ -448,6 +448,62 @@ def dac_decoder(cfg: ParlerTTSConfig, sd, z: torch.Tensor) -> torch.Tensor:
     return torch.tanh(x)
 
 
+def dac_encoder(cfg: ParlerTTSConfig, sd, audio: torch.Tensor) -> torch.Tensor:
+    """descript DAC encoder conv stack (third party; structure per HF:models/dac/modeling_dac.py DacEncoder /
+    DacEncoderBlock / DacResidualUnit): audio [B, 1, T] (T a multiple of the hop) -> latent [B, latent, T / hop]."""
+    a = cfg.audio_encoder
+    p = "audio_encoder.model.encoder.block."
+    h = F.conv1d(audio, sd[p + "0.weight"], sd[p + "0.bias"], padding=3)
+    strides = list(reversed(a.upsampling_ratios))
+    for n, stride in enumerate(strides, start=1):
+        b = f"{p}{n}.block."
+        for r, dil in zip((0, 1, 2), (1, 3, 9)):
+            u = f"{b}{r}.block."
+            y = F.conv1d(snake(h, sd[u + "0.alpha"]), sd[u + "1.weight"], sd[u + "1.bias"], dilation=dil, padding=3 * dil)
+            y = F.conv1d(snake(y, sd[u + "2.alpha"]), sd[u + "3.weight"], sd[u + "3.bias"])
+            h = h + y
+        h = F.conv1d(snake(h, sd[b + "3.alpha"]), sd[b + "4.weight"], sd[b + "4.bias"], stride=stride, padding=math.ceil(stride / 2))
+    R = len(strides)
+    return F.conv1d(snake(h, sd[f"{p}{R + 1}.alpha"]), sd[f"{p}{R + 2}.weight"], sd[f"{p}{R + 2}.bias"], padding=1)
+
+
+def dac_quantize(cfg: ParlerTTSConfig, sd, z: torch.Tensor, margins: Optional[list] = None) -> torch.Tensor:
+    """Residual vector quantisation, encode direction (HF DacResidualVectorQuantizer.forward in eval mode +
+    DacVectorQuantize.decode_latents): per codebook project to codebook_dim, L2-normalise encodings and codebook,
+    nearest entry, subtract its out-projection from the residual.  latent [B, latent, F] -> codes [B, K, F]."""
+    a = cfg.audio_encoder
+    p = "audio_encoder.model.quantizer.quantizers."
+    residual = z
+    codes = []
+    for i in range(a.num_codebooks):
+        ze = F.conv1d(residual, sd[f"{p}{i}.in_proj.weight"], sd[f"{p}{i}.in_proj.bias"])          # [B, 8, F]
+        Bz, Dz, Fz = ze.shape
+        enc = F.normalize(ze.permute(0, 2, 1).reshape(Bz * Fz, Dz))
+        cb = F.normalize(sd[f"{p}{i}.codebook.weight"])
+        dist = -(enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cb.t()) + cb.pow(2).sum(1, keepdim=True).t()
+        idx = dist.max(1)[1].reshape(Bz, Fz)
+        if margins is not None:      # top-2 gap of every nearest-entry decision (fixture bookkeeping)
+            t2 = torch.topk(dist, 2, dim=1)[0]
+            margins.append(float((t2[:, 0] - t2[:, 1]).min()))
+        codes.append(idx)
+        zq = F.embedding(idx, sd[f"{p}{i}.codebook.weight"]).transpose(1, 2)                         # [B, 8, F]
+        zq = F.conv1d(zq, sd[f"{p}{i}.out_proj.weight"], sd[f"{p}{i}.out_proj.bias"])
+        residual = residual - zq
+    return torch.stack(codes, dim=1)
+
+
+def dac_encode(cfg: ParlerTTSConfig, sd, input_values: torch.Tensor) -> torch.Tensor:
+    """DACModel.encode (D:25-96) with chunking disabled: preprocess = right-pad to a multiple of the hop length
+    (descript DAC.preprocess), encoder, quantizer.  input_values [B, 1, T] -> audio_codes [1, B, K, ceil(T / hop)]."""
+    hop = 1
+    for s_ in cfg.audio_encoder.upsampling_ratios:
+        hop *= s_
+    T = input_values.shape[-1]
+    pad = (-T) % hop
+    x = F.pad(input_values.float(), (0, pad))
+    return dac_quantize(cfg, sd, dac_encoder(cfg, sd, x))[None, ...]
+
+
 def dac_decode(cfg: ParlerTTSConfig, sd, audio_codes: torch.Tensor) -> torch.Tensor:
     """DACModel.decode, D:98-134.  audio_codes [1,B,K,F] -> audio_values [B,1,F*hop]."""
     if len(audio_codes) != 1:

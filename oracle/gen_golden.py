@@ -20,7 +20,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from oracle import ref_shim  # noqa: E402
+from oracle import cpu_ref, ref_shim  # noqa: E402
 from parler_tts_amd.configuration import mini_v01_config, tiny_config  # noqa: E402
 from parler_tts_amd.weights import synthetic_state_dict  # noqa: E402
 
@@ -138,11 +138,43 @@ def dac_cases():
         save(name, codes=codes, latent=z, wav=wav, seed=seed)
 
 
+def dac_encode_cases():
+    """codec ENCODE (audio prompts, D:25-96) vs the installed transformers DacModel.encode; the input seed is scanned until
+    every nearest-codebook-entry decision has a top-2 distance gap >= 1e-4, so that bit-exact codes are a fair demand on an
+    implementation whose fp32 sums associate differently."""
+    from parler_tts_amd.weights import synthetic_dac_encoder_state_dict
+
+    for name, cfg, seed, B, T in (("dac_enc_tiny", tiny_config(), 13, 2, 16 * 37 + 5), ("dac_enc_mini", mini_v01_config(), 23, 2, 512 * 12 + 100)):
+        sd = synthetic_state_dict(cfg, seed=seed, parts=("audio_encoder",))
+        sd.update(synthetic_dac_encoder_state_dict(cfg.audio_encoder, seed=seed))
+        hf = ref_shim.build_hf_dac(cfg, sd)
+        hop = int(np.prod(cfg.audio_encoder.upsampling_ratios))
+        for seed_in in range(200, 260):
+            gg = torch.Generator().manual_seed(seed_in)
+            audio = (torch.rand(B, 1, T, generator=gg) * 2 - 1) * 0.5
+            x = torch.nn.functional.pad(audio, (0, (-T) % hop))
+            ms = []
+            z = cpu_ref.dac_encoder(cfg, sd, x)
+            codes = cpu_ref.dac_quantize(cfg, sd, z, margins=ms)
+            if min(ms) >= 1e-4:
+                break
+        else:
+            raise RuntimeError("no seed met the margin")
+        with torch.no_grad():
+            hc = hf.encode(x).audio_codes
+        assert torch.equal(hc, codes), "oracle dac_encode differs from transformers DacModel.encode"
+        print(f"  {name}: seed_in={seed_in} min top-2 distance gap {min(ms):.2e}, codes {tuple(codes.shape)}")
+        save(name, audio=audio, codes=codes[None, ...], latent=z, seed=seed, seed_in=seed_in, min_margin=min(ms))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if "--only-dac" in sys.argv:
         dac_cases()
+        return
+    if "--only-dac-encode" in sys.argv:
+        dac_encode_cases()
         return
     ref = ref_shim.load_reference()
 

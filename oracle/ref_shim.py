@@ -193,7 +193,7 @@ def build_hf_dac(cfg, state_dict):
     hf_cfg = DacConfig(n_codebooks=a.num_codebooks, codebook_size=a.codebook_size, codebook_dim=a.codebook_dim,
                        hidden_size=a.latent_dim, decoder_hidden_size=a.decoder_hidden_size,
                        upsampling_ratios=list(a.upsampling_ratios), downsampling_ratios=list(reversed(a.upsampling_ratios)),
-                       encoder_hidden_size=max(a.decoder_hidden_size // 2 ** len(a.upsampling_ratios) , 8))
+                       encoder_hidden_size=getattr(a, "encoder_hidden_size", max(a.decoder_hidden_size // 2 ** len(a.upsampling_ratios), 8)))
     m = DacModel(hf_cfg).eval()
     p = "audio_encoder.model."
     own = m.state_dict()
@@ -218,6 +218,28 @@ def build_hf_dac(cfg, state_dict):
             new[e + "snake2.alpha"] = state_dict[u + "2.alpha"]
             new[e + "conv2.weight"] = state_dict[u + "3.weight"]
             new[e + "conv2.bias"] = state_dict[u + "3.bias"]
+    if p + "encoder.block.0.weight" in state_dict:      # encode side (audio prompts)
+        new["encoder.conv1.weight"] = state_dict[p + "encoder.block.0.weight"]
+        new["encoder.conv1.bias"] = state_dict[p + "encoder.block.0.bias"]
+        for n in range(1, R + 1):
+            s_, d_ = f"{p}encoder.block.{n}.block.", f"encoder.block.{n - 1}."
+            for r in (0, 1, 2):
+                u, e = f"{s_}{r}.block.", f"{d_}res_unit{r + 1}."
+                new[e + "snake1.alpha"] = state_dict[u + "0.alpha"]
+                new[e + "conv1.weight"] = state_dict[u + "1.weight"]
+                new[e + "conv1.bias"] = state_dict[u + "1.bias"]
+                new[e + "snake2.alpha"] = state_dict[u + "2.alpha"]
+                new[e + "conv2.weight"] = state_dict[u + "3.weight"]
+                new[e + "conv2.bias"] = state_dict[u + "3.bias"]
+            new[d_ + "snake1.alpha"] = state_dict[s_ + "3.alpha"]
+            new[d_ + "conv1.weight"] = state_dict[s_ + "4.weight"]
+            new[d_ + "conv1.bias"] = state_dict[s_ + "4.bias"]
+        new["encoder.snake1.alpha"] = state_dict[f"{p}encoder.block.{R + 1}.alpha"]
+        new["encoder.conv2.weight"] = state_dict[f"{p}encoder.block.{R + 2}.weight"]
+        new["encoder.conv2.bias"] = state_dict[f"{p}encoder.block.{R + 2}.bias"]
+        for i in range(a.num_codebooks):
+            new[f"quantizer.quantizers.{i}.in_proj.weight"] = state_dict[f"{p}quantizer.quantizers.{i}.in_proj.weight"]
+            new[f"quantizer.quantizers.{i}.in_proj.bias"] = state_dict[f"{p}quantizer.quantizers.{i}.in_proj.bias"]
     new["decoder.snake1.alpha"] = state_dict[f"{p}decoder.model.{R + 1}.alpha"]
     new["decoder.conv2.weight"] = state_dict[f"{p}decoder.model.{R + 2}.weight"]
     new["decoder.conv2.bias"] = state_dict[f"{p}decoder.model.{R + 2}.bias"]

@@ -187,8 +187,10 @@ class DACConfig(_ConfigBase):
         decoder_hidden_size: int = 1536,
         upsampling_ratios=(8, 8, 4, 2),
         codebook_dim: int = 8,
+        encoder_hidden_size: int = 64,
         **kwargs,
     ):
+        self.encoder_hidden_size = encoder_hidden_size    # descript `encoder_dim` default; strides = reversed(upsampling_ratios)
         self.codebook_size = codebook_size
         self.model_bitrate = model_bitrate
         self.latent_dim = latent_dim
@@ -375,7 +377,7 @@ def tiny_config(num_codebooks: int = 4, hidden: int = 128, layers: int = 2, head
     )
     t5 = T5EncoderConfig(vocab_size=512, d_model=enc_d, d_kv=32, d_ff=128, num_layers=2, num_heads=2)
     dac = DACConfig(num_codebooks=num_codebooks, codebook_size=codebook_size, latent_dim=64,
-                    decoder_hidden_size=256, upsampling_ratios=(4, 2, 2, 2), codebook_dim=8)
+                    decoder_hidden_size=256, upsampling_ratios=(4, 2, 2, 2), encoder_hidden_size=16, codebook_dim=8)
     return ParlerTTSConfig.from_sub_models_config(
         t5, dac, dec, vocab_size=512, pad_token_id=codebook_size, decoder_start_token_id=codebook_size + 1
     )

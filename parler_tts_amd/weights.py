@@ -131,6 +131,64 @@ def dac_decoder_keys(cfg: DACConfig) -> Dict[str, tuple]:
     return keys
 
 
+def dac_encoder_keys(cfg: DACConfig) -> Dict[str, tuple]:
+    """Folded (plain ``weight``) form of the descript DAC ENCODE-side parameters (audio prompts, D:25-96).
+
+    descript layout: ``encoder.block.0`` first conv (1 -> d), ``encoder.block.{n}`` n=1..R encoder blocks
+    (``block.{0,1,2}`` residual units each ``block.{0,2}`` snake / ``block.{1,3}`` conv, ``block.3`` snake,
+    ``block.4`` strided conv d -> 2d with kernel 2s), ``encoder.block.{R+1}`` snake, ``encoder.block.{R+2}`` last conv
+    (k=3, -> latent); ``quantizer.quantizers.{i}.in_proj`` (latent -> codebook_dim).  Strides are the upsampling ratios
+    reversed.  Kept out of :func:`all_keys` on purpose: synthetic values are keyed by enumeration index."""
+    p = "audio_encoder.model."
+    keys: Dict[str, tuple] = {}
+    d = cfg.encoder_hidden_size
+    keys[f"{p}encoder.block.0.weight"] = (d, 1, 7)
+    keys[f"{p}encoder.block.0.bias"] = (d,)
+    strides = list(reversed(cfg.upsampling_ratios))
+    for n, stride in enumerate(strides, start=1):
+        b = f"{p}encoder.block.{n}.block."
+        for r in (0, 1, 2):
+            keys[f"{b}{r}.block.0.alpha"] = (1, d, 1)
+            keys[f"{b}{r}.block.1.weight"] = (d, d, 7)
+            keys[f"{b}{r}.block.1.bias"] = (d,)
+            keys[f"{b}{r}.block.2.alpha"] = (1, d, 1)
+            keys[f"{b}{r}.block.3.weight"] = (d, d, 1)
+            keys[f"{b}{r}.block.3.bias"] = (d,)
+        keys[f"{b}3.alpha"] = (1, d, 1)
+        keys[f"{b}4.weight"] = (2 * d, d, 2 * stride)
+        keys[f"{b}4.bias"] = (2 * d,)
+        d *= 2
+    R = len(strides)
+    keys[f"{p}encoder.block.{R + 1}.alpha"] = (1, d, 1)
+    keys[f"{p}encoder.block.{R + 2}.weight"] = (cfg.latent_dim, d, 3)
+    keys[f"{p}encoder.block.{R + 2}.bias"] = (cfg.latent_dim,)
+    for i in range(cfg.num_codebooks):
+        keys[f"{p}quantizer.quantizers.{i}.in_proj.weight"] = (cfg.codebook_dim, cfg.latent_dim, 1)
+        keys[f"{p}quantizer.quantizers.{i}.in_proj.bias"] = (cfg.codebook_dim,)
+    return keys
+
+
+def synthetic_dac_encoder_state_dict(cfg: DACConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded encode-side codec weights (own PCG64 streams, offset 1_000_000, so the decode-side values of
+    :func:`synthetic_state_dict` are untouched).  Fan-in scaled so that activations stay O(1) through the stack."""
+    sd: Dict[str, torch.Tensor] = {}
+    for i, (name, shape) in enumerate(dac_encoder_keys(cfg).items()):
+        rng = np.random.Generator(np.random.PCG64([seed, 1_000_000 + i]))
+        a = rng.standard_normal(int(np.prod(shape)), dtype=np.float32).reshape(shape)
+        if name.endswith(".alpha"):
+            a = a * np.float32(0.1) + np.float32(1.0)
+        elif name.endswith(".bias"):
+            a = a * np.float32(0.02)
+        elif ".in_proj." in name:
+            a = a * np.float32(shape[1] ** -0.5)
+        elif name.count(".block.") == 3:
+            a = a * np.float32(0.3 * (shape[1] * shape[2]) ** -0.5)       # residual units
+        else:
+            a = a * np.float32(1.0 * (shape[1] * shape[2]) ** -0.5)       # first / strided / last conv
+        sd[name] = torch.from_numpy(a)
+    return sd
+
+
 def all_keys(cfg: ParlerTTSConfig) -> Dict[str, tuple]:
     keys = dict(t5_keys(cfg.text_encoder))
     keys["embed_prompts.weight"] = (cfg.vocab_size, cfg.decoder.hidden_size)

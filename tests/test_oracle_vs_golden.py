@@ -146,3 +146,30 @@ def test_codes_to_waveform_sequential_path():
     assert (wav[1, 5 * hop:] == 0).all() and wav[1, : 5 * hop].abs().sum() > 0
     full = cpu_ref.dac_decode(cfg, sd, codes[:, :1])[0, 0]
     assert torch.allclose(wav[0], full, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["dac_enc_tiny", "dac_enc_mini"])
+def test_dac_encode_oracle_matches_hf_dac_fixture(name):
+    """Codec ENCODE side (audio prompts, dac_wrapper/modeling_dac.py:25-96): the CPU restatement of the
+    encoder conv stack + residual vector quantisation reproduces the codes that transformers' DacModel.encode produced for
+    the same synthetic weights (fixture written by oracle/gen_golden.py --only-dac-encode).  This is groundwork: the HIP
+    path does not serve `input_values` yet, the oracle it will be checked against is already pinned."""
+    from oracle import cpu_ref
+    from parler_tts_amd.weights import dac_encoder_keys, synthetic_dac_encoder_state_dict, synthetic_state_dict
+    from tests.helpers import config_for
+
+    f, _ = load_case(name)
+    cfg = config_for("mini" if name.endswith("mini") else "tiny")
+    seed = int(f["seed"])
+    sd = synthetic_state_dict(cfg, seed=seed, parts=("audio_encoder",))
+    enc = synthetic_dac_encoder_state_dict(cfg.audio_encoder, seed=seed)
+    assert set(enc) == set(dac_encoder_keys(cfg.audio_encoder)) and not (set(enc) & set(sd))
+    sd.update(enc)
+    audio = torch.from_numpy(f["audio"])
+    codes = cpu_ref.dac_encode(cfg, sd, audio)
+    assert codes.shape == f["codes"].shape
+    assert np.array_equal(codes.numpy(), f["codes"])
+    assert float(f["min_margin"]) >= 1e-4
+    # and the decode side inverts the quantiser's bookkeeping: from_codes(codes) is the quantised latent the encoder saw
+    z = cpu_ref.dac_from_codes(cfg, sd, codes[0])
+    assert z.shape == f["latent"].shape
