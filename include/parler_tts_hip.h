@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 4
+#define PTTS_ABI_VERSION 5
 
 enum { PTTS_DTYPE_F32 = 0, PTTS_DTYPE_BF16 = 1 };
 
@@ -64,6 +64,8 @@ typedef struct ptts_config {
     /* codec decoder (DACConfig + the descript package defaults); dac_hidden = 0: engine without the codec */
     int32_t dac_codebook_size, dac_codebook_dim, dac_latent, dac_hidden, dac_n_up;
     int32_t dac_up[8];          /* upsampling strides, e.g. 8,8,4,2 */
+    /* codec encoder (audio prompts): descript `encoder_dim` (64); its strides are dac_up reversed; 0 = engine without it */
+    int32_t dac_enc_hidden;
 } ptts_config;
 
 typedef struct ptts_engine ptts_engine;
@@ -121,6 +123,14 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
  *      call (and any call needing a larger workspace) allocates two ping-pong activation buffers. ---- */
 int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, float* out, void* stream);
 
+/* ---- codec, encode direction: DACModel.encode (dac_wrapper/modeling_dac.py:25-96) as generate() calls it for audio
+ *      prompts (`input_values`, modeling_parler_tts.py:2247-2292, :2483-2487) = the descript DAC encoder conv stack +
+ *      the residual vector quantiser.  audio [B][T] fp32 (one channel), codes [B][K][T / hop] int64 (floor: the
+ *      reference cuts the preprocess padding off again before it encodes, :85-86, and every strided conv floors).
+ *      Same conv kernels as the decode side; a stride-s conv with kernel 2s is a 3-tap conv over the [T/s][s*C] view of
+ *      its channels-last input.  Shares the workspace of ptts_dac_decode. ---- */
+int ptts_dac_encode(ptts_engine* e, int32_t B, int32_t T, const float* audio, int64_t* codes, void* stream);
+
 /* Sampling parameters of the third-party GenerationMixin step the reference calls at
  * modeling_parler_tts.py:2582 (greedy) / :2608 (sample).  */
 typedef struct ptts_sampling {
@@ -173,7 +183,8 @@ int ptts_set_forced_tokens(ptts_engine* e, const int64_t* tokens_host, int32_t r
 
 /* Debug hooks for kernel-level parity tests: stop issuing kernels after n launches of each following
  * prefill / decode call (-1 = off; while on, steps run eagerly), and expose engine-owned buffers
- * ("x", "q", "attn_frag", "mlp_frag", "enc_h", "self_pool", "cross_pool", "self_bias", "cross_bias", "tok_in"). */
+ * ("x", "q", "attn_frag", "mlp_frag", "enc_h", "self_pool", "cross_pool", "self_bias", "cross_bias", "tok_in",
+ * "codec_latent" = the encoder output [b][F][latent] of the last ptts_dac_encode chunk). */
 int ptts_debug_stop_after(ptts_engine* e, int32_t n_kernels);
 int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* bytes);
 

@@ -450,7 +450,7 @@ def dac_decoder(cfg: ParlerTTSConfig, sd, z: torch.Tensor) -> torch.Tensor:
 
 def dac_encoder(cfg: ParlerTTSConfig, sd, audio: torch.Tensor) -> torch.Tensor:
     """descript DAC encoder conv stack (third party; structure per HF:models/dac/modeling_dac.py DacEncoder /
-    DacEncoderBlock / DacResidualUnit): audio [B, 1, T] (T a multiple of the hop) -> latent [B, latent, T / hop]."""
+    DacEncoderBlock / DacResidualUnit): audio [B, 1, T] -> latent [B, latent, T // hop] (each strided conv floors)."""
     a = cfg.audio_encoder
     p = "audio_encoder.model.encoder.block."
     h = F.conv1d(audio, sd[p + "0.weight"], sd[p + "0.bias"], padding=3)
@@ -493,15 +493,15 @@ def dac_quantize(cfg: ParlerTTSConfig, sd, z: torch.Tensor, margins: Optional[li
 
 
 def dac_encode(cfg: ParlerTTSConfig, sd, input_values: torch.Tensor) -> torch.Tensor:
-    """DACModel.encode (D:25-96) with chunking disabled: preprocess = right-pad to a multiple of the hop length
-    (descript DAC.preprocess), encoder, quantizer.  input_values [B, 1, T] -> audio_codes [1, B, K, ceil(T / hop)]."""
-    hop = 1
-    for s_ in cfg.audio_encoder.upsampling_ratios:
-        hop *= s_
-    T = input_values.shape[-1]
-    pad = (-T) % hop
-    x = F.pad(input_values.float(), (0, pad))
-    return dac_quantize(cfg, sd, dac_encoder(cfg, sd, x))[None, ...]
+    """DACModel.encode (D:25-96) with chunking disabled.  D:56 right-pads to a multiple of the hop length
+    (descript DAC.preprocess), but the single chunk is then cut as ``audio_data[:, :, 0:input_length]`` (D:64-66, D:85-86:
+    chunk_length = stride = input_length), so the encoder sees the audio at its ORIGINAL length and descript's
+    ``DAC.encode`` (encoder + quantizer, no padding of its own) yields floor(T / hop) frames.
+    input_values [B, 1, T] -> audio_codes [1, B, K, T // hop]."""
+    _, channels, T = input_values.shape
+    if channels < 1 or channels > 2:
+        raise ValueError(f"Number of audio channels must be 1 or 2, but got {channels}")       # D:53-54
+    return dac_quantize(cfg, sd, dac_encoder(cfg, sd, input_values.float()))[None, ...]
 
 
 def dac_decode(cfg: ParlerTTSConfig, sd, audio_codes: torch.Tensor) -> torch.Tensor:

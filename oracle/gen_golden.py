@@ -152,16 +152,15 @@ def dac_encode_cases():
         for seed_in in range(200, 260):
             gg = torch.Generator().manual_seed(seed_in)
             audio = (torch.rand(B, 1, T, generator=gg) * 2 - 1) * 0.5
-            x = torch.nn.functional.pad(audio, (0, (-T) % hop))
             ms = []
-            z = cpu_ref.dac_encoder(cfg, sd, x)
+            z = cpu_ref.dac_encoder(cfg, sd, audio)    # original length: D:85-86 cut the preprocess padding off again
             codes = cpu_ref.dac_quantize(cfg, sd, z, margins=ms)
             if min(ms) >= 1e-4:
                 break
         else:
             raise RuntimeError("no seed met the margin")
         with torch.no_grad():
-            hc = hf.encode(x).audio_codes
+            hc = hf.encode(audio).audio_codes
         assert torch.equal(hc, codes), "oracle dac_encode differs from transformers DacModel.encode"
         print(f"  {name}: seed_in={seed_in} min top-2 distance gap {min(ms):.2e}, codes {tuple(codes.shape)}")
         save(name, audio=audio, codes=codes[None, ...], latent=z, seed=seed, seed_in=seed_in, min_margin=min(ms))

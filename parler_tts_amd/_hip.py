@@ -11,13 +11,13 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libparler_tts_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 # every symbol include/parler_tts_hip.h declares (tests check the export table against this list)
 EXPORTS = [
     "ptts_last_error", "ptts_abi_version", "ptts_create", "ptts_destroy", "ptts_load_tensor", "ptts_weights_ready",
-    "ptts_t5_encode", "ptts_dac_decode", "ptts_set_prompt_embeds", "ptts_prefill", "ptts_decode_steps", "ptts_forward_step", "ptts_select_step", "ptts_get_state", "ptts_last_logits",
+    "ptts_t5_encode", "ptts_dac_decode", "ptts_dac_encode", "ptts_set_prompt_embeds", "ptts_prefill", "ptts_decode_steps", "ptts_forward_step", "ptts_select_step", "ptts_get_state", "ptts_last_logits",
     "ptts_set_block_table", "ptts_pool_info", "ptts_set_forced_tokens", "ptts_profile_read", "ptts_test_gemm",
     "ptts_debug_stop_after", "ptts_debug_buffer",
 ]
@@ -35,6 +35,7 @@ class PttsConfig(C.Structure):
         ("max_batch", C.c_int32), ("max_desc_len", C.c_int32), ("max_prompt_len", C.c_int32), ("max_length", C.c_int32),
         ("dac_codebook_size", C.c_int32), ("dac_codebook_dim", C.c_int32), ("dac_latent", C.c_int32),
         ("dac_hidden", C.c_int32), ("dac_n_up", C.c_int32), ("dac_up", C.c_int32 * 8),
+        ("dac_enc_hidden", C.c_int32),
     ]
 
 
@@ -83,6 +84,7 @@ def load_library() -> C.CDLL:
     lib.ptts_weights_ready.argtypes = [vp]
     lib.ptts_t5_encode.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.ptts_dac_decode.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.ptts_dac_encode.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.ptts_set_prompt_embeds.argtypes = [vp, vp]
     lib.ptts_prefill.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.ptts_decode_steps.argtypes = [vp, i32, C.POINTER(PttsSampling), i32, vp]

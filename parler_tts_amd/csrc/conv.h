@@ -17,6 +17,7 @@ struct ConvArgs {
     int taps = 1, tstep = 1, toff = 0;
     int stride = 1, pad_t = 0;     // transposed: t = stride*u - pad_t + n / Cout
     int act_out = 0;               // 1 = tanh
+    size_t in_bs = 0, out_bs = 0;  // floats between utterances of in / out (and res); 0 = dense (Tin*Cin, Tout*Cout)
 };
 
 hipError_t conv_init();
@@ -28,3 +29,29 @@ hipError_t dac_table_launch(const float* codebook, const float* proj_w, const fl
 hipError_t split_halves_launch(const float* src, void* hi, void* lo, size_t n, hipStream_t s);
 hipError_t conv_pack_launch(const float* w, float* out, int Cout, int Cin, int k, int transposed, int stride, int N,
                             hipStream_t s);
+
+// ---- codec ENCODE side (audio prompts, dac_wrapper/modeling_dac.py:25-96) ----
+// first conv of the encoder: one input channel, k = 7, zero padding 3: out[b][t][c] = bias[c] + sum_k w[c][k] * x[b][t+k-3]
+hipError_t enc_first_conv_launch(const float* audio, const float* w, const float* bias, float* out, int B, int T, int C,
+                                 size_t out_bs, hipStream_t s);
+// buf[b*bs + i] = 0 for i in [from, to): the rows a [T/s][s*C] view reads past the true length must be zero (Snake(0) = 0)
+hipError_t zero_tail_launch(float* buf, int B, size_t bs, size_t from, size_t to, hipStream_t s);
+// Conv1d(C -> N, kernel 2s, stride s, padding ceil(s/2)) as a 3-tap stride-1 conv over the [T/s][s*C] view of its input:
+// out[tap][n][j*C + c] = w[n][c][(tap-1)*s + j + pad] (0 outside the kernel), taps at rows t-1, t, t+1
+hipError_t conv_pack_strided_launch(const float* w, float* out, int N, int C, int stride, hipStream_t s);
+hipError_t tile_alpha_launch(const float* alpha, float* out, int C, int reps, hipStream_t s);
+// L2-normalised codebook rows (F.normalize, eps 1e-12) and their squared norms
+hipError_t cb_normalize_launch(const float* cb, float* cbn, float* cbn2, int entries, int dim, hipStream_t s);
+struct RvqArgs {
+    const float* z = nullptr;            // [B][F][D] latent, channels-last
+    int B = 0, F = 0, D = 0, K = 0, entries = 0, dim = 0;
+    const float* const* in_w = nullptr;  // [K] -> [dim][D]
+    const float* const* in_b = nullptr;  // [K] -> [dim]
+    const float* const* cb = nullptr;    // [K] -> [entries][dim] raw codebook
+    const float* const* cbn = nullptr;   // [K] -> normalised rows
+    const float* const* cbn2 = nullptr;  // [K] -> [entries]
+    const float* const* out_w = nullptr; // [K] -> [D][dim]
+    const float* const* out_b = nullptr; // [K] -> [D]
+    long long* codes = nullptr;          // [B][K][F]
+};
+hipError_t rvq_encode_launch(const RvqArgs& a, hipStream_t s);

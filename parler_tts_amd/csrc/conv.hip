@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = {0, 0, 0, 0};
 
-    const float* inb = a.in + (size_t)b * a.Tin * a.Cin;
+    const float* inb = a.in + (size_t)b * (a.in_bs ? a.in_bs : (size_t)a.Tin * a.Cin);
     for (int c0 = 0; c0 < a.Cin; c0 += KC) {
         // ---- stage the input window (Snake applied once per element) ----
         for (int i = tid; i < win * (KC / 4); i += 256) {
@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: bias, residual, tanh; channels-last stores of 4 consecutive outputs ----
-    float* outb = a.out + (size_t)b * a.Tout * a.Cout;
-    const float* resb = a.res ? a.res + (size_t)b * a.Tout * a.Cout : nullptr;
+    const size_t obs = a.out_bs ? a.out_bs : (size_t)a.Tout * a.Cout;
+    float* outb = a.out + (size_t)b * obs;
+    const float* resb = a.res ? a.res + (size_t)b * obs : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int u = u0 + w * 32 + i * 16 + (lane & 15);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = {0, 0, 0, 0};
 
-    const float* inb = a.in + (size_t)b * a.Tin * a.Cin;
+    const float* inb = a.in + (size_t)b * (a.in_bs ? a.in_bs : (size_t)a.Tin * a.Cin);
     const _Float16* gwh = reinterpret_cast<const _Float16*>(a.w_hi);
     const _Float16* gwl = reinterpret_cast<const _Float16*>(a.w_lo);
 
@@ -289,8 +290,9 @@ __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
     }
 
     // ---- epilogue (same as the fp32 kernel) ----
-    float* outb = a.out + (size_t)b * a.Tout * a.Cout;
-    const float* resb = a.res ? a.res + (size_t)b * a.Tout * a.Cout : nullptr;
+    const size_t obs = a.out_bs ? a.out_bs : (size_t)a.Tout * a.Cout;
+    float* outb = a.out + (size_t)b * obs;
+    const float* resb = a.res ? a.res + (size_t)b * obs : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int u = u0 + w * 32 + i * 16 + (lane & 15);
@@ -376,6 +378,116 @@ __global__ void conv_pack_kernel(const float* w, float* out, int Cout, int Cin, 
     out[idx] = v;
 }
 
+
+// ---- codec ENCODE side ----------------------------------------------------------------------------------------------
+__global__ void enc_first_conv_kernel(const float* __restrict__ audio, const float* __restrict__ w, const float* __restrict__ bias,
+                                      float* __restrict__ out, int T, int C, size_t out_bs) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;    // (t, c)
+    if (i >= (size_t)T * C) return;
+    const int t = (int)(i / C), c = (int)(i % C);
+    const float* x = audio + (size_t)b * T;
+    float acc = bias[c];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int tt = t + k - 3;
+        if (tt >= 0 && tt < T) acc = fmaf(w[c * 7 + k], x[tt], acc);
+    }
+    out[(size_t)b * out_bs + (size_t)t * C + c] = acc;
+}
+
+__global__ void zero_tail_kernel(float* buf, size_t bs, size_t from, size_t to) {
+    const size_t i = from + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < to) buf[(size_t)blockIdx.y * bs + i] = 0.f;
+}
+
+__global__ void conv_pack_strided_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int C, int stride) {
+    const int Ce = stride * C, pad = (stride + 1) / 2;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)3 * N * Ce) return;
+    const int ce = (int)(idx % Ce), n = (int)((idx / Ce) % N), tap = (int)(idx / ((size_t)Ce * N));
+    const int j = ce / C, c = ce % C;
+    const int k = (tap - 1) * stride + j + pad;
+    out[idx] = (k >= 0 && k < 2 * stride) ? w[((size_t)n * C + c) * (2 * stride) + k] : 0.f;
+}
+
+__global__ void tile_alpha_kernel(const float* __restrict__ alpha, float* __restrict__ out, int C, int reps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C * reps) out[i] = alpha[i % C];
+}
+
+__global__ void cb_normalize_kernel(const float* __restrict__ cb, float* __restrict__ cbn, float* __restrict__ cbn2, int entries, int dim) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= entries) return;
+    float ss = 0.f;
+    for (int d = 0; d < dim; ++d) ss += cb[j * dim + d] * cb[j * dim + d];
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    float s2 = 0.f;
+    for (int d = 0; d < dim; ++d) { const float v = cb[j * dim + d] / nrm; cbn[j * dim + d] = v; s2 += v * v; }
+    cbn2[j] = s2;
+}
+
+// Residual vector quantisation of one frame per workgroup (256 threads): for every codebook project the residual to
+// `dim` (in_proj), L2-normalise, take the nearest normalised codebook entry (first maximum of
+// -(|e|^2 - 2 e.c) + |c|^2, as DacVectorQuantize.decode_latents computes it), subtract out_proj(codebook[idx]).
+__global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* r = reinterpret_cast<float*>(smem);             // [D] residual
+    __shared__ float part[4][16];
+    __shared__ float ze[16];
+    __shared__ float bestv[4];
+    __shared__ int besti[4];
+    const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int D = a.D, dim = a.dim;
+    for (int d = tid; d < D; d += 256) r[d] = a.z[((size_t)b * a.F + f) * D + d];
+    __syncthreads();
+    for (int k = 0; k < a.K; ++k) {
+        // in_proj: dim dot products of length D
+        const float* W = a.in_w[k];
+        for (int o = 0; o < dim; ++o) {
+            float acc = 0.f;
+            for (int d = tid; d < D; d += 256) acc = fmaf(W[(size_t)o * D + d], r[d], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) part[w][o] = acc;
+        }
+        __syncthreads();
+        if (tid < dim) ze[tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + a.in_b[k][tid];
+        __syncthreads();
+        float e[16], l2 = 0.f, ss = 0.f;
+        for (int o = 0; o < dim; ++o) ss += ze[o] * ze[o];
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        for (int o = 0; o < dim; ++o) { e[o] = ze[o] / nrm; l2 += e[o] * e[o]; }
+        // nearest entry: first index of the maximum
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        const float* cn = a.cbn[k];
+        for (int j = tid; j < a.entries; j += 256) {
+            float dot = 0.f;
+            for (int o = 0; o < dim; ++o) dot = fmaf(e[o], cn[(size_t)j * dim + o], dot);
+            const float dist = -(l2 - 2.f * dot) + a.cbn2[k][j];
+            if (dist > bv || (dist == bv && j < bi)) { bv = dist; bi = j; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { bestv[w] = bv; besti[w] = bi; }
+        __syncthreads();
+        bv = bestv[0]; bi = besti[0];
+        for (int i = 1; i < 4; ++i) if (bestv[i] > bv || (bestv[i] == bv && besti[i] < bi)) { bv = bestv[i]; bi = besti[i]; }
+        if (tid == 0) a.codes[((size_t)b * a.K + k) * a.F + f] = bi;
+        // residual -= out_proj(codebook[idx]) (+ bias)
+        const float* cq = a.cb[k] + (size_t)bi * dim;
+        const float* Wo = a.out_w[k];
+        for (int d = tid; d < D; d += 256) {
+            float acc = a.out_b[k][d];
+            for (int o = 0; o < dim; ++o) acc = fmaf(Wo[(size_t)d * dim + o], cq[o], acc);
+            r[d] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 hipError_t conv_init() {
@@ -444,5 +556,35 @@ hipError_t conv_pack_launch(const float* w, float* out, int Cout, int Cin, int k
 
 hipError_t split_halves_launch(const float* src, void* hi, void* lo, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(split_halves_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (_Float16*)hi, (_Float16*)lo, n);
+    return hipGetLastError();
+}
+
+hipError_t enc_first_conv_launch(const float* audio, const float* w, const float* bias, float* out, int B, int T, int C,
+                                 size_t out_bs, hipStream_t s) {
+    dim3 grid((unsigned)(((size_t)T * C + 255) / 256), B);
+    hipLaunchKernelGGL(enc_first_conv_kernel, grid, dim3(256), 0, s, audio, w, bias, out, T, C, out_bs ? out_bs : (size_t)T * C);
+    return hipGetLastError();
+}
+hipError_t zero_tail_launch(float* buf, int B, size_t bs, size_t from, size_t to, hipStream_t s) {
+    if (to <= from) return hipSuccess;
+    hipLaunchKernelGGL(zero_tail_kernel, dim3((unsigned)((to - from + 255) / 256), B), dim3(256), 0, s, buf, bs, from, to);
+    return hipGetLastError();
+}
+hipError_t conv_pack_strided_launch(const float* w, float* out, int N, int C, int stride, hipStream_t s) {
+    const size_t total = (size_t)3 * N * stride * C;
+    hipLaunchKernelGGL(conv_pack_strided_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, N, C, stride);
+    return hipGetLastError();
+}
+hipError_t tile_alpha_launch(const float* alpha, float* out, int C, int reps, hipStream_t s) {
+    hipLaunchKernelGGL(tile_alpha_kernel, dim3((C * reps + 255) / 256), dim3(256), 0, s, alpha, out, C, reps);
+    return hipGetLastError();
+}
+hipError_t cb_normalize_launch(const float* cb, float* cbn, float* cbn2, int entries, int dim, hipStream_t s) {
+    hipLaunchKernelGGL(cb_normalize_kernel, dim3((entries + 255) / 256), dim3(256), 0, s, cb, cbn, cbn2, entries, dim);
+    return hipGetLastError();
+}
+hipError_t rvq_encode_launch(const RvqArgs& a, hipStream_t s) {
+    if (a.dim > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3(a.F, a.B), dim3(256), (size_t)a.D * sizeof(float), s, a);
     return hipGetLastError();
 }

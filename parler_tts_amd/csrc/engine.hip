@@ -75,6 +75,7 @@ struct ConvLayer {
     void *w_hi = nullptr, *w_lo = nullptr;                    // fp16 hi/lo split of `w` (fast conv path)
     int Cin = 0, Cout = 0, k = 1, dil = 1, stride = 1;
     bool transposed = false, have_w = false, have_b = false, have_a = false, needs_alpha = false;
+    bool strided = false;   // encoder down-sampling conv (kernel 2*stride): run as a 3-tap conv over the [T/s][s*Cin] view
 };
 
 struct EventPair {
@@ -132,6 +133,14 @@ struct ptts_engine {
     std::vector<float*> dac_codebook, dac_proj_w, dac_proj_b;
     float* dac_table = nullptr;
     bool dac_table_ready = false;
+    // DAC encoder (audio prompts): first conv (1 -> d) kept apart, then per block {3 x (conv7, conv1), strided conv}, last conv (k=3)
+    std::vector<ConvLayer> enc;
+    float *enc0_w = nullptr, *enc0_b = nullptr;
+    std::vector<float*> dac_in_w, dac_in_b, dac_cbn, dac_cbn2;
+    const float** rvq_ptrs = nullptr;   // device copy of the 7 per-codebook pointer arrays RvqArgs wants
+    bool rvq_ready = false;
+    float* enc_latent = nullptr;        // debug: latent of the last ptts_dac_encode chunk
+    size_t enc_latent_bytes = 0;
     float *dac_buf0 = nullptr, *dac_buf1 = nullptr;
     bool dac_f32_only = false;   // PTTS_DAC_F32=1: keep every conv on the fp32 MFMA kernel (cross-check)
     size_t dac_buf_floats = 0;
@@ -484,6 +493,85 @@ int dac_layer_index(const ptts_engine* e, int n, int r, int sub) {
     return -1;
 }
 
+
+// encoder.block.{n}...: n=0 first conv; n=1..R blocks {block.{0,1,2} residual units (block.{0,2} snake, block.{1,3} conv),
+// block.3 snake, block.4 strided conv}; n=R+1 snake; n=R+2 last conv.  e->enc index: (n-1)*7 + {2r, 2r+1, 6}; last = 7R.
+int load_dac_encoder_tensor(ptts_engine* e, const std::string& n, const float* data, const int64_t* shape, int ndim, size_t numel,
+                            hipStream_t s) {
+    const ptts_config& c = e->cfg;
+    const int R = c.dac_n_up;
+    int idx = 0, r = -1, sub = -1;
+    std::string rest;
+    if (!parse_idx(n, "encoder.block.", &idx, &rest)) return 1;
+    if (idx == 0) {
+        const int d = c.dac_enc_hidden;
+        if (rest == "weight") {
+            if (numel != (size_t)d * 7) return fail(PTTS_E_INVALID, "encoder.block.0.weight size %zu != %d", numel, d * 7);
+            if (!e->enc0_w) PTTS_TRY(dev_alloc(e, (void**)&e->enc0_w, numel * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(e->enc0_w, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else if (rest == "bias") {
+            if (numel != (size_t)d) return fail(PTTS_E_INVALID, "encoder.block.0.bias size %zu != %d", numel, d);
+            if (!e->enc0_b) PTTS_TRY(dev_alloc(e, (void**)&e->enc0_b, numel * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(e->enc0_b, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else return 1;
+        return PTTS_OK;
+    }
+    int li = -1;
+    bool is_alpha = false;
+    std::string leaf = rest;
+    if (idx >= 1 && idx <= R) {
+        std::string r2;
+        if (!parse_idx(rest, "block.", &r, &r2)) return 1;
+        const int base = (idx - 1) * 7;
+        if (r >= 0 && r <= 2) {
+            std::string r3;
+            if (!parse_idx(r2, "block.", &sub, &r3)) return 1;
+            leaf = r3;
+            if (sub == 0 || sub == 2) { is_alpha = true; li = base + 2 * r + (sub == 2 ? 1 : 0); }
+            else if (sub == 1 || sub == 3) li = base + 2 * r + (sub == 3 ? 1 : 0);
+            else return 1;
+        } else if (r == 3) { leaf = r2; is_alpha = true; li = base + 6; }
+        else if (r == 4) { leaf = r2; li = base + 6; }
+        else return 1;
+    } else if (idx == R + 1) { is_alpha = true; li = 7 * R; }
+    else if (idx == R + 2) li = 7 * R;
+    else return 1;
+    ConvLayer& L = e->enc[li];
+    if (is_alpha) {
+        if (leaf != "alpha") return 1;
+        if (numel != (size_t)L.Cin) return fail(PTTS_E_INVALID, "alpha size %zu != %d", numel, L.Cin);
+        const int reps = L.strided ? L.stride : 1;
+        if (!L.alpha) PTTS_TRY(dev_alloc(e, (void**)&L.alpha, numel * reps * sizeof(float)));
+        HIP_TRY(tile_alpha_launch(data, L.alpha, L.Cin, reps, s));
+        L.have_a = true;
+        return PTTS_OK;
+    }
+    if (leaf == "bias") {
+        if (numel != (size_t)L.Cout) return fail(PTTS_E_INVALID, "bias size %zu != %d", numel, L.Cout);
+        if (!L.bias) PTTS_TRY(dev_alloc(e, (void**)&L.bias, numel * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(L.bias, data, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+        L.have_b = true;
+        return PTTS_OK;
+    }
+    if (leaf == "weight") {
+        if (ndim != 3 || shape[0] != L.Cout || shape[1] != L.Cin || shape[2] != L.k)
+            return fail(PTTS_E_INVALID, "conv weight shape mismatch for encoder.block.%d", idx);
+        const int taps = L.strided ? 3 : L.k;
+        const int cin_eff = L.strided ? L.stride * L.Cin : L.Cin;
+        const size_t cnt = (size_t)taps * L.Cout * cin_eff;
+        if (!L.w) PTTS_TRY(dev_alloc(e, (void**)&L.w, cnt * sizeof(float)));
+        if (L.strided) HIP_TRY(conv_pack_strided_launch(data, L.w, L.Cout, L.Cin, L.stride, s));
+        else HIP_TRY(conv_pack_launch(data, L.w, L.Cout, L.Cin, L.k, 0, 1, L.Cout, s));
+        if (cin_eff % 32 == 0 && !e->dac_f32_only) {
+            if (!L.w_hi) { PTTS_TRY(dev_alloc(e, &L.w_hi, cnt * 2)); PTTS_TRY(dev_alloc(e, &L.w_lo, cnt * 2)); }
+            HIP_TRY(split_halves_launch(L.w, L.w_hi, L.w_lo, cnt, s));
+        }
+        L.have_w = true;
+        return PTTS_OK;
+    }
+    return 1;
+}
+
 // returns 0 ok, 1 unknown name, <0 error
 int load_dac_tensor(ptts_engine* e, const std::string& n, const float* data, const int64_t* shape, int ndim, hipStream_t s) {
     const ptts_config& c = e->cfg;
@@ -498,15 +586,21 @@ int load_dac_tensor(ptts_engine* e, const std::string& n, const float* data, con
         if (rest == "codebook.weight") { dst = &e->dac_codebook[idx]; want = (size_t)c.dac_codebook_size * c.dac_codebook_dim; }
         else if (rest == "out_proj.weight") { dst = &e->dac_proj_w[idx]; want = (size_t)c.dac_latent * c.dac_codebook_dim; }
         else if (rest == "out_proj.bias") { dst = &e->dac_proj_b[idx]; want = (size_t)c.dac_latent; }
-        else if (rest.compare(0, 8, "in_proj.") == 0) return PTTS_OK;   // encode side, unused
+        else if (rest == "in_proj.weight" || rest == "in_proj.bias") {
+            if (e->enc.empty()) return PTTS_OK;                         // engine without the encode side
+            const bool isw = rest == "in_proj.weight";
+            dst = isw ? &e->dac_in_w[idx] : &e->dac_in_b[idx];
+            want = isw ? (size_t)c.dac_codebook_dim * c.dac_latent : (size_t)c.dac_codebook_dim;
+        }
         else return 1;
         if (numel != want) return fail(PTTS_E_INVALID, "quantizer tensor size %zu != %zu", numel, want);
         if (!*dst) PTTS_TRY(dev_alloc(e, (void**)dst, want * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(*dst, data, want * sizeof(float), hipMemcpyDeviceToDevice, s));
         e->dac_table_ready = false;
+        e->rvq_ready = false;
         return PTTS_OK;
     }
-    if (n.compare(0, 8, "encoder.") == 0) return PTTS_OK;   // DAC encoder: not on the decode path
+    if (n.compare(0, 8, "encoder.") == 0) return e->enc.empty() ? PTTS_OK : load_dac_encoder_tensor(e, n, data, shape, ndim, numel, s);
     if (!parse_idx(n, "decoder.model.", &idx, &rest)) return 1;
     const int R = c.dac_n_up;
     int r = -1, sub = -1;
@@ -634,6 +728,32 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
         e->dac_codebook.assign(cfg->codebooks, nullptr);
         e->dac_proj_w.assign(cfg->codebooks, nullptr);
         e->dac_proj_b.assign(cfg->codebooks, nullptr);
+        if (cfg->dac_enc_hidden > 0) {   // encode side: widths d, 2d, ... 2^R d; strides = the up-sampling ratios reversed
+            if (cfg->dac_enc_hidden % 16 != 0 || cfg->dac_codebook_dim > 16) {
+                delete e;
+                return fail(PTTS_E_UNSUPPORTED, "codec encoder: hidden must be a multiple of 16, codebook_dim <= 16");
+            }
+            int d = cfg->dac_enc_hidden;
+            for (int i = 0; i < cfg->dac_n_up; ++i) {
+                const int st = cfg->dac_up[cfg->dac_n_up - 1 - i];
+                const int dils[3] = {1, 3, 9};
+                for (int r = 0; r < 3; ++r) {
+                    ConvLayer a7; a7.Cin = d; a7.Cout = d; a7.k = 7; a7.dil = dils[r]; a7.needs_alpha = true;
+                    ConvLayer a1; a1.Cin = d; a1.Cout = d; a1.k = 1; a1.needs_alpha = true;
+                    e->enc.push_back(a7);
+                    e->enc.push_back(a1);
+                }
+                ConvLayer sc; sc.Cin = d; sc.Cout = 2 * d; sc.k = 2 * st; sc.stride = st; sc.strided = true; sc.needs_alpha = true;
+                e->enc.push_back(sc);
+                d *= 2;
+            }
+            ConvLayer fin; fin.Cin = d; fin.Cout = cfg->dac_latent; fin.k = 3; fin.needs_alpha = true;
+            e->enc.push_back(fin);
+            e->dac_in_w.assign(cfg->codebooks, nullptr);
+            e->dac_in_b.assign(cfg->codebooks, nullptr);
+            e->dac_cbn.assign(cfg->codebooks, nullptr);
+            e->dac_cbn2.assign(cfg->codebooks, nullptr);
+        }
     }
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete e;
@@ -1161,6 +1281,102 @@ int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, 
     return leave_stream(e, stream, s);
 }
 
+int ptts_dac_encode(ptts_engine* e, int32_t B, int32_t T, const float* audio, int64_t* codes, void* stream) {
+    if (!e || !audio || !codes) return fail(PTTS_E_INVALID, "null argument");
+    if (e->enc.empty()) return fail(PTTS_E_STATE, "engine was created without the codec encoder (dac_enc_hidden = 0)");
+    const ptts_config& c = e->cfg;
+    int hop = 1;
+    for (int i = 0; i < c.dac_n_up; ++i) hop *= c.dac_up[i];
+    if (B <= 0 || T < hop) return fail(PTTS_E_INVALID, "B=%d T=%d: need at least one hop (%d samples)", B, T, hop);
+    if (!e->enc0_w || !e->enc0_b) return fail(PTTS_E_STATE, "codec encoder: first conv is missing tensors");
+    for (size_t i = 0; i < e->enc.size(); ++i) {
+        const ConvLayer& L = e->enc[i];
+        if (!L.have_w || !L.have_b || !L.have_a) return fail(PTTS_E_STATE, "codec encoder layer %zu is missing tensors", i);
+    }
+    const int K = c.codebooks;
+    for (int k = 0; k < K; ++k)
+        if (!e->dac_codebook[k] || !e->dac_proj_w[k] || !e->dac_proj_b[k] || !e->dac_in_w[k] || !e->dac_in_b[k])
+            return fail(PTTS_E_STATE, "quantizer %d is missing tensors", k);
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
+    if (!e->rvq_ready) {   // normalised codebooks + the pointer arrays of the quantiser kernel
+        std::vector<const float*> host((size_t)7 * K);
+        for (int k = 0; k < K; ++k) {
+            const size_t cb = (size_t)c.dac_codebook_size * c.dac_codebook_dim;
+            if (!e->dac_cbn[k]) {
+                PTTS_TRY(dev_alloc(e, (void**)&e->dac_cbn[k], cb * sizeof(float)));
+                PTTS_TRY(dev_alloc(e, (void**)&e->dac_cbn2[k], (size_t)c.dac_codebook_size * sizeof(float)));
+            }
+            HIP_TRY(cb_normalize_launch(e->dac_codebook[k], e->dac_cbn[k], e->dac_cbn2[k], c.dac_codebook_size, c.dac_codebook_dim, s));
+            host[0 * K + k] = e->dac_in_w[k]; host[1 * K + k] = e->dac_in_b[k]; host[2 * K + k] = e->dac_codebook[k];
+            host[3 * K + k] = e->dac_cbn[k];  host[4 * K + k] = e->dac_cbn2[k]; host[5 * K + k] = e->dac_proj_w[k];
+            host[6 * K + k] = e->dac_proj_b[k];
+        }
+        if (!e->rvq_ptrs) PTTS_TRY(dev_alloc(e, (void**)&e->rvq_ptrs, host.size() * sizeof(float*)));
+        HIP_TRY(hipMemcpyAsync(e->rvq_ptrs, host.data(), host.size() * sizeof(float*), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));   // `host` is a stack temporary
+        e->rvq_ready = true;
+    }
+    // One slab per utterance, channels-last: (T + hop) * d floats bounds every layer's activation and the zeroed tail a
+    // strided layer's [T/s][s*C] view reads (widths double while lengths shrink by >= 2).
+    const int d0 = c.dac_enc_hidden;
+    const int F = T / hop;
+    size_t slab = ((size_t)T + hop) * d0;
+    if (slab < (size_t)F * c.dac_latent) slab = (size_t)F * c.dac_latent;
+    const size_t budget = (size_t)12 << 30;
+    int chunk = (int)(budget / (slab * sizeof(float)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > B) chunk = B;
+    const size_t need = slab * chunk;
+    if (need > e->dac_buf_floats) {   // the codec workspace is shared with ptts_dac_decode
+        HIP_TRY(hipStreamSynchronize(s));
+        if (e->dac_buf0) (void)hipFree(e->dac_buf0);
+        if (e->dac_buf1) (void)hipFree(e->dac_buf1);
+        e->dac_buf0 = e->dac_buf1 = nullptr; e->dac_buf_floats = 0;
+        if (hipMalloc((void**)&e->dac_buf0, need * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&e->dac_buf1, need * sizeof(float)) != hipSuccess)
+            return fail(PTTS_E_NOMEM, "codec workspace of 2 x %zu bytes", need * sizeof(float));
+        e->dac_buf_floats = need;
+    }
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        float* cur = e->dac_buf0;
+        float* nxt = e->dac_buf1;
+        HIP_TRY(enc_first_conv_launch(audio + (size_t)b0 * T, e->enc0_w, e->enc0_b, cur, nb, T, d0, slab, s));
+        int Tl = T;   // true length of the current activation
+        for (size_t i = 0; i < e->enc.size(); ++i) {
+            const ConvLayer& L = e->enc[i];
+            const bool last = i + 1 == e->enc.size();
+            ConvArgs a;
+            a.in = cur; a.w = L.w; a.w_hi = L.w_hi; a.w_lo = L.w_lo; a.bias = L.bias; a.alpha = L.alpha;
+            a.B = nb; a.in_bs = slab; a.out_bs = slab; a.Cout = L.Cout; a.N = L.Cout;
+            if (L.strided) {
+                const int st = L.stride, rows = (Tl + st - 1) / st;
+                HIP_TRY(zero_tail_launch(cur, nb, slab, (size_t)Tl * L.Cin, (size_t)rows * st * L.Cin, s));
+                a.Tin = rows; a.Cin = st * L.Cin; a.Tout = Tl / st; a.U = a.Tout; a.taps = 3; a.tstep = 1; a.toff = -1;
+                a.out = nxt;
+            } else {
+                a.Tin = Tl; a.Cin = L.Cin; a.Tout = Tl; a.U = Tl; a.taps = L.k; a.tstep = L.dil; a.toff = -((L.k - 1) * L.dil) / 2;
+                if (L.k == 1) { a.out = nxt; a.res = nxt; }      // residual unit: add into the unit's input in place
+                else a.out = nxt;
+                if (last) a.out_bs = (size_t)F * c.dac_latent;   // dense latent [nb][F][latent] for the quantiser
+            }
+            HIP_TRY(conv_launch(a, s));
+            if (L.strided) Tl = a.Tout;
+            std::swap(cur, nxt);
+        }
+        if (Tl != F) return fail(PTTS_E_INVALID, "internal: encoder produced %d frames, expected %d", Tl, F);
+        e->enc_latent = cur; e->enc_latent_bytes = (size_t)nb * F * c.dac_latent * sizeof(float);
+        RvqArgs q;
+        q.z = cur; q.B = nb; q.F = F; q.D = c.dac_latent; q.K = K; q.entries = c.dac_codebook_size; q.dim = c.dac_codebook_dim;
+        q.in_w = e->rvq_ptrs; q.in_b = e->rvq_ptrs + K; q.cb = e->rvq_ptrs + 2 * K; q.cbn = e->rvq_ptrs + 3 * K;
+        q.cbn2 = e->rvq_ptrs + 4 * K; q.out_w = e->rvq_ptrs + 5 * K; q.out_b = e->rvq_ptrs + 6 * K;
+        q.codes = (long long*)codes + (size_t)b0 * K * F;
+        HIP_TRY(rvq_encode_launch(q, s));
+    }
+    return leave_stream(e, stream, s);
+}
+
 int ptts_debug_stop_after(ptts_engine* e, int32_t n_kernels) {
     if (!e) return fail(PTTS_E_INVALID, "null engine");
     e->dbg_stop = n_kernels;
@@ -1181,6 +1397,7 @@ int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* byt
     else if (n == "cross_pool") { *ptr = e->cross_pool; *bytes = (int64_t)c.max_batch * e->cross_blocks * c.layers * 2 * c.heads * 4096 * e->esz; }
     else if (n == "cross_bias") { *ptr = e->cross_bias; *bytes = (int64_t)c.max_batch * e->cross_blocks * 64 * 4; }
     else if (n == "self_bias") { *ptr = e->self_bias; *bytes = (int64_t)c.max_batch * e->s_cap * 4; }
+    else if (n == "codec_latent") { *ptr = e->enc_latent; *bytes = (int64_t)e->enc_latent_bytes; }
     else if (n == "tok_in") { *ptr = e->tok_in; *bytes = rows * c.codebooks * 4; }
     else return fail(PTTS_E_INVALID, "unknown buffer '%s'", name);
     return PTTS_OK;

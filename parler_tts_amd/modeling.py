@@ -74,6 +74,7 @@ class HipEngine:
         d, t5 = cfg.decoder, cfg.text_encoder
         self.codec_only = codec_only
         self.has_codec = any(k.startswith("audio_encoder.model.decoder.") for k in state_dict)
+        self.has_codec_encoder = False
         if codec_only:
             with_t5 = False
         c = _hip.PttsConfig()
@@ -98,6 +99,9 @@ class HipEngine:
             c.dac_hidden, c.dac_n_up = a.decoder_hidden_size, len(a.upsampling_ratios)
             for i, r in enumerate(a.upsampling_ratios):
                 c.dac_up[i] = int(r)
+            # encode side (audio prompts) only when its tensors came with the checkpoint
+            self.has_codec_encoder = "audio_encoder.model.encoder.block.0.weight" in state_dict
+            c.dac_enc_hidden = int(getattr(a, "encoder_hidden_size", 64)) if self.has_codec_encoder else 0
         self.limits = (max_batch, max_desc_len, max_prompt_len, max_length)
         self.cfg = cfg
         self.handle = C.c_void_p()
@@ -166,6 +170,20 @@ class HipEngine:
         _hip.check(self.lib.ptts_dac_decode(self.handle, B, F, _ptr(codes), _ptr(out), _stream()))
         torch.cuda.current_stream().synchronize()   # `codes` may be a temporary
         return out
+
+    def dac_encode(self, audio: torch.Tensor) -> torch.Tensor:
+        """audio [B, T] fp32 -> codes [B, K, T // hop] int64 (ptts_dac_encode)."""
+        if not self.has_codec_encoder:
+            raise RuntimeError("this checkpoint holds no codec encoder weights (audio_encoder.model.encoder.*)")
+        B, T = audio.shape
+        a = self.cfg.audio_encoder
+        if T < a.hop_length:
+            raise ValueError(f"audio prompt of {T} samples is shorter than one codec frame ({a.hop_length})")
+        audio = audio.to(self.device, torch.float32).contiguous()
+        codes = torch.empty(B, a.num_codebooks, T // a.hop_length, device=self.device, dtype=torch.int64)
+        _hip.check(self.lib.ptts_dac_encode(self.handle, B, T, _ptr(audio), _ptr(codes), _stream()))
+        torch.cuda.current_stream().synchronize()   # `audio` may be a temporary
+        return codes
 
     def prefill(self, B, B_eff, enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, start_len,
                 prompt_embeds=None):
@@ -260,8 +278,8 @@ class DACModel:
     """Codec wrapper with the reference's ``decode`` contract (dac_wrapper/modeling_dac.py:98-134):
     ``audio_codes [1, B, K, F]`` -> ``audio_values [B, 1, F * hop]``.  The arithmetic (quantizer.from_codes +
     the DAC decoder conv stack) runs in ``ptts_dac_decode`` (csrc/conv.hip: implicit-GEMM MFMA kernels with
-    fused Snake / bias / residual / tanh).  ``encode`` (audio prompts, training pre-processing) is outside
-    the accelerated path."""
+    fused Snake / bias / residual / tanh).  ``encode`` (D:25-96, audio prompts) runs the encoder conv stack and the
+    residual vector quantiser in ``ptts_dac_encode``."""
 
     config_class = DACConfig
 
@@ -300,8 +318,25 @@ class DACModel:
         wav = self._engine().dac_decode(codes)
         return ModelOutput(audio_values=wav[:, None, :])
 
-    def encode(self, *a, **k):
-        raise NotImplementedError("DACModel.encode (audio prompts) is a SURVEY section-8(f) 'next' row")
+    @torch.no_grad()
+    def encode(self, input_values, padding_mask=None, bandwidth=None, return_dict=None, n_quantizers=None, sample_rate=None):
+        """D:25-96: ``input_values [B, channels, T]`` -> ``audio_codes [1, B, K, T // hop]`` (+ ``audio_scales [None]``).
+        One chunk (the reference hard-codes chunk_length = None, D:62-66); the encoder sees the audio at its original
+        length (D:85-86 cut the preprocess padding off again).  ``padding_mask`` / ``bandwidth`` are unused as there."""
+        if input_values.dim() != 3:
+            raise ValueError("input_values must be [batch, channels, samples]")
+        _, channels, _ = input_values.shape
+        if channels < 1 or channels > 2:
+            raise ValueError(f"Number of audio channels must be 1 or 2, but got {channels}")      # D:53-54
+        if channels != 1:
+            raise ValueError("the DAC encoder's first convolution takes one channel")               # descript: Conv1d(1, d, 7)
+        if n_quantizers is not None and n_quantizers != self.config.num_codebooks:
+            raise NotImplementedError("n_quantizers < num_codebooks is not on the generate() path")
+        codes = self._engine().dac_encode(input_values[:, 0])
+        out = ModelOutput(audio_codes=codes[None, ...], audio_scales=[None])
+        if return_dict is False:
+            return (out.audio_codes, out.audio_scales)
+        return out
 
     def forward(self, tensor):
         raise ValueError("`DACModel.forward` not implemented yet")   # same message as the reference (D:136-137)
@@ -402,11 +437,11 @@ class ParlerTTSForConditionalGeneration:
         logits_processor = list(logits_processor) if logits_processor else []
         stopping_criteria = list(stopping_criteria) if stopping_criteria else []
         allowed = {"input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "encoder_outputs",
-                   "prompt_hidden_states", "decoder_input_ids", "return_raw_ids"}
-        unsupported = {"input_values", "decoder_attention_mask"}
+                   "prompt_hidden_states", "decoder_input_ids", "return_raw_ids", "input_values", "padding_mask"}
+        unsupported = {"decoder_attention_mask"}
         for k in model_kwargs:
             if k in unsupported:
-                raise NotImplementedError(f"`{k}` (audio prompts) is a SURVEY 8(f) 'next' row")
+                raise NotImplementedError(f"`{k}` is a SURVEY 8(f) 'next' row")
             if k not in allowed:
                 raise ValueError(f"The following `model_kwargs` are not used by the model: ['{k}']")
         if gen.pad_token_id is None and gen.eos_token_id is not None:   # M:2432-2442
@@ -445,6 +480,19 @@ class ParlerTTSForConditionalGeneration:
         start_tok = gen.decoder_start_token_id if gen.decoder_start_token_id is not None else gen.bos_token_id
         ids = torch.full((B * K, 1), start_tok, dtype=torch.long, device=dev)
         dec_in = model_kwargs.get("decoder_input_ids")
+        if dec_in is None and model_kwargs.get("input_values") is not None:
+            # audio prompt (M:2483-2487 -> M:2247-2292): codec ids of the waveform become the decoder prefix
+            if self._engine is None:   # size the engine for the whole call before the codec runs on it
+                n_pre = model_kwargs["input_values"].shape[-1] // cfgm.audio_encoder.hop_length + 1
+                L_est = gen.max_new_tokens + n_pre if gen.max_new_tokens is not None else int(gen.max_length)
+                if P + L_est <= dec.max_position_embeddings:
+                    self.engine(B_eff, T, P, L_est)
+            enc_codes = self.audio_encoder.encode(model_kwargs["input_values"].to(dev)).audio_codes
+            frames, bsz, codebooks, seq_len = enc_codes.shape
+            if frames != 1:
+                raise ValueError(f"Expected 1 frame in the audio code outputs, got {frames} frames. Ensure chunking is "
+                                 "disabled by setting `chunk_length=None` in the audio encoder.")
+            dec_in = enc_codes[0].reshape(bsz * K, seq_len)
         if dec_in is not None:       # user prefix [B*K, s]; the start column is prepended when it is missing (M:2184-2185)
             dec_in = dec_in.to(dev, torch.long)
             if dec_in.dim() != 2 or dec_in.shape[0] != B * K:

@@ -355,7 +355,15 @@ def normalize_state_dict(sd: Dict[str, torch.Tensor], cfg: ParlerTTSConfig) -> D
     for k, shape in want.items():
         if tuple(sd[k].shape) != tuple(shape):
             raise ValueError(f"{k}: expected shape {tuple(shape)}, found {tuple(sd[k].shape)}")
-    return {k: sd[k] for k in want}
+    out = {k: sd[k] for k in want}
+    # codec ENCODE side (audio prompts): optional as a block - a real checkpoint carries all of it
+    enc = dac_encoder_keys(cfg.audio_encoder)
+    if all(k in sd for k in enc):
+        for k, shape in enc.items():
+            if tuple(sd[k].shape) != tuple(shape):
+                raise ValueError(f"{k}: expected shape {tuple(shape)}, found {tuple(sd[k].shape)}")
+            out[k] = sd[k]
+    return out
 
 
 def save_pretrained(path: str, cfg: ParlerTTSConfig, sd: Dict[str, torch.Tensor], generation_config=None) -> None:
