@@ -38,5 +38,8 @@ struct FullAttnArgs {
 };
 
 hipError_t attn_init();
-hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream);
+// ev_start / ev_stop (both or neither): bound to the dispatch itself through hipExtLaunchKernel, so their elapsed time is the
+// kernel's own begin -> end (what a profiler reports), without barrier packets around it
+hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream,
+                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t attn_full_launch(const FullAttnArgs& a, int B, int out_dtype, hipStream_t stream);

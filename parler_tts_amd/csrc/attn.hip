@@ -19,6 +19,7 @@
 // (utterance, head), no LDS, no barrier; it also finishes the look-ahead query projection (LayerNorm
 // correction from per-block row statistics).
 #include "ptts_common.h"
+#include <hip/hip_ext.h>
 #include "attn.h"
 #include <cstdlib>
 
@@ -419,7 +420,8 @@ hipError_t attn_init() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream) {
+hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream, hipEvent_t ev_start,
+                              hipEvent_t ev_stop) {
     if (!a.no_page_kernel && !a.len_from_state && a.len <= PTTS_PAGE_TOKENS) {
         dim3 pgrid((H + 3) / 4, B), pblock(256);
         if (cache_dtype == PTTS_BF16) {
@@ -435,7 +437,12 @@ hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, 
     dim3 grid(H, B), block(NWAVES * 64);
 #define PTTS_ATTN_LAUNCH(P_, O_)                                                                             \
     do {                                                                                                     \
-        if (a.len_from_state) hipLaunchKernelGGL((attn_decode_kernel<P_, O_, true>), grid, block, lds, stream, a); \
+        /* profiled launches: events bound to THIS dispatch (its own start / end timestamps, no barrier packets) */ \
+        if (ev_start && a.len_from_state)                                                                    \
+            hipExtLaunchKernelGGL((attn_decode_kernel<P_, O_, true>), grid, block, (uint32_t)lds, stream, ev_start, ev_stop, 0, a); \
+        else if (ev_start)                                                                                   \
+            hipExtLaunchKernelGGL((attn_decode_kernel<P_, O_, false>), grid, block, (uint32_t)lds, stream, ev_start, ev_stop, 0, a); \
+        else if (a.len_from_state) hipLaunchKernelGGL((attn_decode_kernel<P_, O_, true>), grid, block, lds, stream, a); \
         else hipLaunchKernelGGL((attn_decode_kernel<P_, O_, false>), grid, block, lds, stream, a);            \
     } while (0)
     if (cache_dtype == PTTS_BF16) {

@@ -325,11 +325,10 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
             ep = &e->ev_pool[e->ev_used++];
             ep->kind = 0;
             ep->bytes = 2.0 * M * (double)(e->host_pos + 1) * D * (double)e->esz;
-            HIP_TRY(hipEventRecord(ep->a, s));
         }
         DBG_GATE(e);
-        HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
-        if (ep) HIP_TRY(hipEventRecord(ep->b, s));
+        // sampled launches carry their own start / stop events (hipExtLaunchKernel): the dispatch's timestamps
+        HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr));
         // out_proj + residual (M:380, M:460)
         const bool look = e->look_active;
         g = GemmArgs();
