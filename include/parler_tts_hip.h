@@ -99,6 +99,13 @@ int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_id
  * completed; NULL restores the id lookup. */
 int ptts_set_prompt_embeds(ptts_engine* e, const float* embeds);
 
+/* `decoder_attention_mask` (modeling_parler_tts.py:845-846: concatenated behind prompt_attention_mask, then the 4-D causal
+ * mask of :870-872; the third-party loop appends a column of ones per generated token): mask [B_eff][start_len] int32
+ * over the prefix columns (start column included), consumed by the NEXT ptts_prefill, which gives the cache positions
+ * P .. P+start_len-1 of masked columns the additive finfo.min bias; kept alive by the caller until that prefill has
+ * completed; NULL = none. */
+int ptts_set_decoder_mask(ptts_engine* e, const int32_t* mask);
+
 /* ---- prefill: everything generate() does before the token loop (modeling_parler_tts.py:2467-2537)
  *      plus the first forward pass over the prompt (decoder forward M:794-978 with P+1 positions):
  *      enc_to_dec_proj + mask (M:2010-2017), cross K/V of every layer (M:295-298), prompt embedding

@@ -166,6 +166,7 @@ def decoder_forward(
     prompt_attention_mask: Optional[torch.Tensor],   # [B,P] or None
     cache: KVCache,
     return_hidden: bool = False,
+    decoder_attention_mask: Optional[torch.Tensor] = None,   # [B, past_generated + q_in] or None
 ):
     """ParlerTTSDecoder.forward + 9 LM heads: M:794-978, M:1096-1185.  Returns logits [B*K, q, V]."""
     dec = cfg.decoder
@@ -182,7 +183,11 @@ def decoder_forward(
     dtype = x.dtype
 
     mask2d = None
-    if prompt_attention_mask is not None:                        # M:845-867 (decoder_attention_mask is None)
+    if prompt_attention_mask is not None and decoder_attention_mask is not None:     # M:845-846
+        mask2d = torch.cat([prompt_attention_mask, decoder_attention_mask], dim=1)
+    elif decoder_attention_mask is not None:                     # no prompt mask: the decoder mask alone (M:870-872)
+        mask2d = decoder_attention_mask
+    elif prompt_attention_mask is not None:                      # M:847-867
         if past == 0:
             mask2d = torch.cat([prompt_attention_mask, torch.ones(B, q_in, dtype=prompt_attention_mask.dtype)], 1)
         else:
@@ -313,6 +318,9 @@ def generate_ids(
     step_times: Optional[list] = None,
     logits_processor: Optional[list] = None,
     decoder_input_ids: Optional[torch.Tensor] = None,
+    decoder_attention_mask: Optional[torch.Tensor] = None,
+    prompt_hidden_states: Optional[torch.Tensor] = None,
+    decoder_only: bool = False,
 ) -> Dict[str, torch.Tensor]:
     """The hot loop: M:2530-2537 (delay mask) + prepare_inputs_for_generation M:2081-2148 +
     forward M:1927-2079 + the third-party greedy/sample step.
@@ -336,18 +344,25 @@ def generate_ids(
         if amask is not None:
             amask = torch.cat([amask, torch.zeros_like(amask)], dim=0)
     prompt_h = F.embedding(prompt_input_ids, sd["embed_prompts.weight"]) if prompt_input_ids is not None else None
+    if prompt_hidden_states is not None:          # pre-embedded prompt (M:2476; the decoder-only driver's only form)
+        prompt_h = prompt_hidden_states
     pmask = prompt_attention_mask
     if use_cfg:  # M:2109-2118
         if prompt_h is not None:
             prompt_h = prompt_h.repeat(2, 1, 1)
         if pmask is not None:
             pmask = pmask.repeat(2, 1)
-    enc_h = encoder_glue(cfg, sd, enc, amask)  # constant across steps
+    # decoder-only driver (ParlerTTSForCausalLM.generate, M:1281-1552): encoder_hidden_states go to the decoder as given
+    enc_h = enc if decoder_only else encoder_glue(cfg, sd, enc, amask)  # constant across steps
 
     start_tok = cfg.decoder_start_token_id if cfg.decoder_start_token_id is not None else bos
     ids = torch.full((B * K, 1), start_tok, dtype=torch.long)                    # M:2174-2181
     if decoder_input_ids is not None:                                            # M:2163-2185: user prefix, start column ensured
-        ids = decoder_input_ids if not bool((decoder_input_ids[..., 0] != start_tok).all()) else torch.cat([ids, decoder_input_ids], -1)
+        prepend = bool((decoder_input_ids[..., 0] != start_tok).all())
+        ids = decoder_input_ids if not prepend else torch.cat([ids, decoder_input_ids], -1)
+        if prepend and decoder_attention_mask is not None:                       # M:2186-2193
+            decoder_attention_mask = torch.cat([torch.ones_like(decoder_attention_mask)[:, :1], decoder_attention_mask], -1)
+    dmask = decoder_attention_mask
     ids, pattern = build_delay_pattern_mask(ids, bos, pad, max_length, K)       # M:2530-2535
     cache = KVCache(kv_mode, max_len=(0 if prompt_h is None else prompt_h.shape[1]) + max_length)
     unfinished = torch.ones(B * K, dtype=torch.long)
@@ -359,8 +374,11 @@ def generate_ids(
         model_in = masked if cache.length == 0 else masked[:, -1:]              # M:2120-2130
         if use_cfg:
             model_in = model_in.repeat(2, 1)
+        dm = None if dmask is None else (dmask.repeat(2, 1) if use_cfg else dmask)     # M:2112-2113
         logits = decoder_forward(cfg, sd, model_in, enc_h, amask,
-                                 prompt_h if cache.length == 0 else None, pmask, cache)[:, -1, :]
+                                 prompt_h if cache.length == 0 else None, pmask, cache, decoder_attention_mask=dm)[:, -1, :]
+        if dmask is not None:      # third-party _update_model_kwargs_for_generation: one column of ones per new token
+            dmask = torch.cat([dmask, dmask.new_ones((dmask.shape[0], 1))], dim=-1)
         if use_cfg:
             logits = cfg_combine(logits, guidance_scale)
         for proc in (logits_processor or []):      # user processors follow the guidance processor (M:2556-2567), before the warpers

@@ -81,7 +81,8 @@ def free_margin(r):
     if "margins" not in r:
         return float("inf")
     m = r["margins"]
-    free = (r["pattern"][:, 1:1 + m.shape[0]] == -1).T
+    c0 = r["raw_ids"].shape[1] - m.shape[0]        # step j fills column c0 + j (c0 = 1 without a decoder prefix)
+    free = (r["pattern"][:, c0:c0 + m.shape[0]] == -1).T
     return float(m[free].min()) if bool(free.any()) else float("inf")
 
 
@@ -89,7 +90,7 @@ _models = {}
 
 
 def run_case(name, cfg, sd_kw, B, T, P, L, seed_in, ragged=False, pass_prompt_mask=False, record=0,
-             min_margin=0.0, **gen):
+             min_margin=0.0, _max_attempts=40, **gen):
     """``min_margin``: input seeds are scanned (seed_in, seed_in+1000, ...) until every kept greedy
     argmax of the reference run has a top-2 gap above it, so that bit-exact token parity is a fair
     demand on an implementation whose fp32 sums are ordered differently."""
@@ -98,7 +99,7 @@ def run_case(name, cfg, sd_kw, B, T, P, L, seed_in, ragged=False, pass_prompt_ma
         sd = synthetic_state_dict(cfg, parts=("text_encoder", "decoder"), **sd_kw)
         _models[key] = ref_shim.build_reference_model(cfg, sd)
     model = _models[key]
-    for attempt in range(40):
+    for attempt in range(_max_attempts):
         desc, amask, prompt, pmask = synth_inputs(cfg, B, T, P, seed_in, ragged)
         use_pmask = pmask if (ragged or pass_prompt_mask) else None
         r = ref_shim.reference_generate_ids(model, desc, amask, prompt, use_pmask, L, record_logits=record, **gen)
@@ -114,7 +115,10 @@ def run_case(name, cfg, sd_kw, B, T, P, L, seed_in, ragged=False, pass_prompt_ma
                   max_length=L, free_min_margin=fm, **{k: v for k, v in r.items()})
     arrays["meta"] = json.dumps(dict(sd_kw=sd_kw, B=B, T=T, P=P, L=L, seed_in=seed_in, ragged=ragged,
                                      gen={k: (v if not isinstance(v, dict) else "forced") for k, v in gen.items()
-                                          if k != "generator"}))
+                                          if k != "generator" and not isinstance(v, torch.Tensor)}))
+    for k in ("decoder_input_ids", "decoder_attention_mask"):
+        if gen.get(k) is not None:
+            arrays[k] = gen[k]
     if "forced_tokens" in gen and gen["forced_tokens"]:
         ft = gen["forced_tokens"]
         arrays["forced_steps"] = np.array(sorted(ft.keys()))
@@ -166,8 +170,70 @@ def dac_encode_cases():
         save(name, audio=audio, codes=codes[None, ...], latent=z, seed=seed, seed_in=seed_in, min_margin=min(ms))
 
 
+def prefix_cases():
+    """decoder prefixes (`decoder_input_ids`, M:2150-2195) with and without `decoder_attention_mask` (M:845-846), through the
+    REAL reference forward / prepare_inputs_for_generation / _prepare_decoder_input_ids_for_generation.  The prefix stands for
+    the codec ids of an audio prompt; left-padded rows get pad ids and a zero mask."""
+    tiny = tiny_config()
+    kw = dict(seed=11, never_eos=True, ln_jitter=0.1)
+    K = tiny.decoder.num_codebooks
+    B, s = 3, 6
+    for name, masked in (("tiny_prefix", False), ("tiny_prefix_masked", True)):
+        for attempt in range(40):
+            g = torch.Generator().manual_seed(300 + attempt)
+            prefix = torch.randint(0, tiny.decoder.pad_token_id, (B * K, s), generator=g)
+            dmask = None
+            if masked:
+                dmask = torch.ones(B, s, dtype=torch.long)
+                dmask[1, :2] = 0
+                dmask[2, :4] = 0
+                prefix.reshape(B, K, s)[1, :, :2] = tiny.decoder.pad_token_id
+                prefix.reshape(B, K, s)[2, :, :4] = tiny.decoder.pad_token_id
+            try:
+                r = run_case(name, tiny, kw, B=B, T=9, P=5, L=24, seed_in=105 + 7 * attempt, ragged=masked, record=64,
+                             min_margin=1e-3, decoder_input_ids=prefix, decoder_attention_mask=dmask, _max_attempts=1)
+            except RuntimeError:
+                continue
+            break
+        else:
+            raise RuntimeError("no seed met the margin")
+
+
+def causal_case():
+    """decoder-only driver (ParlerTTSForCausalLM.generate, M:1281-1552): the real class taken out of the composite reference
+    model, conditioned on random encoder / prompt hidden states of the decoder width with ragged masks."""
+    tiny = tiny_config()
+    sd_kw = dict(seed=11, never_eos=True, ln_jitter=0.1)
+    sd = synthetic_state_dict(tiny, parts=("text_encoder", "decoder"), **sd_kw)
+    causal = ref_shim.build_reference_model(tiny, sd).decoder
+    B, T, P, L, D = 3, 9, 5, 24, tiny.decoder.hidden_size
+    for seed_in in range(400, 440):
+        g = torch.Generator().manual_seed(seed_in)
+        enc_h = torch.randn(B, T, D, generator=g)
+        prompt_h = torch.randn(B, P, D, generator=g) * 0.05
+        emask = torch.ones(B, T, dtype=torch.long)
+        emask[1, T - 3:] = 0
+        pmask = torch.ones(B, P, dtype=torch.long)
+        pmask[2, :2] = 0
+        r = ref_shim.reference_causal_generate_ids(causal, enc_h, emask, prompt_h, pmask, L, record_logits=64)
+        fm = free_margin(r)
+        if fm >= 1e-3:
+            break
+    else:
+        raise RuntimeError("no seed met the margin")
+    print(f"  tiny_causal: seed_in={seed_in} free-min margin {fm:.3e}")
+    save("tiny_causal", enc_h=enc_h, emask=emask, prompt_h=prompt_h, pmask=pmask, max_length=L, free_min_margin=fm,
+         meta=json.dumps(dict(sd_kw=sd_kw, B=B, T=T, P=P, L=L, seed_in=seed_in)), **r)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-causal" in sys.argv:
+        causal_case()
+        return
+    if "--only-prefix" in sys.argv:
+        prefix_cases()
+        return
     torch.set_num_threads(8)
     if "--only-dac" in sys.argv:
         dac_cases()

@@ -113,7 +113,8 @@ def build_reference_model(cfg, state_dict):
 @torch.no_grad()
 def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, prompt_attention_mask,
                            max_length, do_sample=False, temperature=1.0, top_k=50, guidance_scale=None,
-                           generator=None, record_logits=0, forced_tokens=None):
+                           generator=None, record_logits=0, forced_tokens=None, decoder_input_ids=None,
+                           decoder_attention_mask=None):
     """Drive the REAL reference ``forward`` (M:1927) + ``prepare_inputs_for_generation`` (M:2081) +
     ``build/apply_delay_pattern_mask`` with the third-party greedy/sample step restated in a few lines
     (transformers 4.3x ``greedy_search``/``sample`` no longer exist).
@@ -139,6 +140,17 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
     if prompt_attention_mask is not None:
         kw["prompt_attention_mask"] = prompt_attention_mask
     ids = torch.full((B * K, 1), dec.bos_token_id, dtype=torch.long)
+    if decoder_input_ids is not None:
+        # the reference's own _prepare_decoder_input_ids_for_generation (M:2150-2195) prepends the start column (and a
+        # ones column to decoder_attention_mask); _get_decoder_start_token_id is gone from transformers 5.x, so the
+        # instance gets the one-line 4.3x body
+        mk = {"decoder_input_ids": decoder_input_ids}
+        if decoder_attention_mask is not None:
+            mk["decoder_attention_mask"] = decoder_attention_mask
+        model._get_decoder_start_token_id = lambda a=None, b=None: a if a is not None else dec.bos_token_id
+        ids, mk = model._prepare_decoder_input_ids_for_generation(B, "input_ids", mk, dec.bos_token_id, dec.bos_token_id, ids.device)
+        if "decoder_attention_mask" in mk:
+            kw["decoder_attention_mask"] = mk["decoder_attention_mask"]
     ids, pattern = model.decoder.build_delay_pattern_mask(ids, dec.bos_token_id, dec.pad_token_id, max_length)
     unf = torch.ones(B * K, dtype=torch.long)
     past = None
@@ -167,6 +179,9 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
             nxt = forced_tokens[step].clone()
         nxt = nxt * unf + dec.pad_token_id * (1 - unf)
         ids = torch.cat([ids, nxt[:, None]], dim=-1)
+        if "decoder_attention_mask" in kw:   # third-party _update_model_kwargs_for_generation (4.3x): a column of ones per token
+            dm = kw["decoder_attention_mask"]
+            kw["decoder_attention_mask"] = torch.cat([dm, dm.new_ones((dm.shape[0], 1))], dim=-1)
         unf = unf * (nxt != dec.eos_token_id).long()
         step += 1
         if int(unf.max()) == 0 or ids.shape[-1] >= max_length:
@@ -183,6 +198,45 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
     if margins:
         res["margins"] = torch.stack(margins)
     return res
+
+
+@torch.no_grad()
+def reference_causal_generate_ids(causal, encoder_hidden_states, encoder_attention_mask, prompt_hidden_states,
+                                  prompt_attention_mask, max_length, record_logits=0):
+    """The decoder-only driver (M:1281-1552) on the REAL ``ParlerTTSForCausalLM``: its ``forward`` (M:1096-1185) and
+    ``prepare_inputs_for_generation`` (M:1187-1247) with the third-party greedy step restated as in
+    ``reference_generate_ids``; un-delay per M:1532-1546."""
+    dec = causal.config
+    K = dec.num_codebooks
+    B = encoder_hidden_states.shape[0]
+    kw = dict(encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
+              prompt_hidden_states=prompt_hidden_states, prompt_attention_mask=prompt_attention_mask, use_cache=True)
+    ids = torch.full((B * K, 1), dec.bos_token_id, dtype=torch.long)
+    ids, pattern = causal.build_delay_pattern_mask(ids, dec.bos_token_id, dec.pad_token_id, max_length)
+    unf = torch.ones(B * K, dtype=torch.long)
+    past, step_logits, margins, step = None, [], [], 0
+    while True:
+        mi = causal.prepare_inputs_for_generation(ids, past_key_values=past, delay_pattern_mask=pattern, **kw)
+        out = causal(**mi, return_dict=True)
+        past = out.past_key_values
+        logits = out.logits[:, -1, :]
+        if step < record_logits:
+            step_logits.append(logits.clone())
+        t2 = torch.topk(logits, 2, dim=-1)[0]
+        margins.append(t2[:, 0] - t2[:, 1])
+        nxt = torch.argmax(logits, dim=-1)
+        nxt = nxt * unf + dec.pad_token_id * (1 - unf)
+        ids = torch.cat([ids, nxt[:, None]], dim=-1)
+        unf = unf * (nxt != dec.eos_token_id).long()
+        step += 1
+        if int(unf.max()) == 0 or ids.shape[-1] >= max_length:
+            break
+    out_ids = causal.apply_delay_pattern_mask(ids, pattern)
+    start = torch.full((B * K, 1), dec.bos_token_id, dtype=torch.long)
+    _, m = causal.build_delay_pattern_mask(start, dec.bos_token_id, dec.pad_token_id, out_ids.shape[1])
+    keep = (m != dec.bos_token_id) & (m != dec.pad_token_id)
+    return {"raw_ids": ids, "pattern": pattern, "codes": out_ids[keep].reshape(B, K, -1),
+            "step_logits": torch.stack(step_logits), "margins": torch.stack(margins)}
 
 
 def build_hf_dac(cfg, state_dict):

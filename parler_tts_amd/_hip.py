@@ -17,7 +17,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 # every symbol include/parler_tts_hip.h declares (tests check the export table against this list)
 EXPORTS = [
     "ptts_last_error", "ptts_abi_version", "ptts_create", "ptts_destroy", "ptts_load_tensor", "ptts_weights_ready",
-    "ptts_t5_encode", "ptts_dac_decode", "ptts_dac_encode", "ptts_set_prompt_embeds", "ptts_prefill", "ptts_decode_steps", "ptts_forward_step", "ptts_select_step", "ptts_get_state", "ptts_last_logits",
+    "ptts_t5_encode", "ptts_dac_decode", "ptts_dac_encode", "ptts_set_prompt_embeds", "ptts_set_decoder_mask", "ptts_prefill", "ptts_decode_steps", "ptts_forward_step", "ptts_select_step", "ptts_get_state", "ptts_last_logits",
     "ptts_set_block_table", "ptts_pool_info", "ptts_set_forced_tokens", "ptts_profile_read", "ptts_test_gemm",
     "ptts_debug_stop_after", "ptts_debug_buffer",
 ]
@@ -86,6 +86,7 @@ def load_library() -> C.CDLL:
     lib.ptts_dac_decode.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.ptts_dac_encode.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.ptts_set_prompt_embeds.argtypes = [vp, vp]
+    lib.ptts_set_decoder_mask.argtypes = [vp, vp]
     lib.ptts_prefill.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.ptts_decode_steps.argtypes = [vp, i32, C.POINTER(PttsSampling), i32, vp]
     lib.ptts_forward_step.argtypes = [vp, vp]

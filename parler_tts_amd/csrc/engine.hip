@@ -155,6 +155,7 @@ struct ptts_engine {
     long long* raw_ids = nullptr;
     const long long* prompt_ids = nullptr;
     const float* prompt_embeds = nullptr;   // one-shot: set by ptts_set_prompt_embeds, consumed by the next prefill
+    const int* dec_mask = nullptr;          // one-shot: set by ptts_set_decoder_mask, [B_eff][start_len]
     int host_pos = 0, host_cur = 0;
     // work stream used when the caller hands us the (uncapturable) legacy NULL stream
     hipStream_t own_stream = nullptr;
@@ -1019,8 +1020,13 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     const int D = c.hidden, M = B_eff * T;
     // additive masks (M:870-879)
     HIP_TRY(build_bias_launch(attention_mask, e->cross_bias, B_eff, T, e->cross_blocks * PTTS_PAGE_TOKENS, s));
-    e->has_self_bias = prompt_mask != nullptr;
-    if (prompt_mask) HIP_TRY(build_bias_launch(prompt_mask, e->self_bias, B_eff, P, e->s_cap, s));
+    e->has_self_bias = prompt_mask != nullptr || e->dec_mask != nullptr;
+    if (e->has_self_bias)   // n_mask = 0 zero-fills (no prompt mask: every prompt key is attended)
+        HIP_TRY(build_bias_launch(prompt_mask ? prompt_mask : attention_mask, e->self_bias, B_eff, prompt_mask ? P : 0, e->s_cap, s));
+    if (e->dec_mask) {      // decoder_attention_mask over the prefix columns = cache positions P .. P + start_len - 1
+        HIP_TRY(build_bias_segment_launch(e->dec_mask, e->self_bias, B_eff, start_len, e->s_cap, P, s));
+        e->dec_mask = nullptr;
+    }
     // enc_to_dec_proj (+bias) then * attention_mask (M:2010-2017); rowmask index = b*T + t = flat mask index
     const float* enc_h = enc_states;
     GemmArgs g;
@@ -1190,6 +1196,12 @@ int ptts_pool_info(ptts_engine* e, int32_t* n_pages, int32_t* max_blocks, int64_
 int ptts_set_prompt_embeds(ptts_engine* e, const float* embeds) {
     if (!e) return fail(PTTS_E_INVALID, "null engine");
     e->prompt_embeds = embeds;
+    return PTTS_OK;
+}
+
+int ptts_set_decoder_mask(ptts_engine* e, const int32_t* mask) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    e->dec_mask = mask;
     return PTTS_OK;
 }
 

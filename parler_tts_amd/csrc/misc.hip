@@ -413,6 +413,14 @@ __global__ void build_bias_kernel(const int* mask, float* bias, int B, int n_mas
     bias[i] = v;
 }
 
+// the same rule for a segment of key positions [offset, offset + n) (decoder_attention_mask over the prefix columns)
+__global__ void build_bias_segment_kernel(const int* mask, float* bias, int B, int n, int ld_bias, int offset) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n) return;
+    int b = i / n, s = i % n;
+    bias[(size_t)b * ld_bias + offset + s] = mask[i] == 0 ? -3.4028234663852886e38f : 0.f;
+}
+
 // encoder states pass through unprojected when the widths match: enc_h = enc * attention_mask (M:2016-2017)
 __global__ void rowmask_mul_kernel(const float* x, const int* rowmask, float* y, int rows, int D) {
     const int r = blockIdx.x;
@@ -475,6 +483,12 @@ hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern
                        rows_eff, L, col);
     return hipGetLastError();
 }
+hipError_t build_bias_segment_launch(const int* mask, float* bias, int B, int n, int ld_bias, int offset, hipStream_t s) {
+    if (B * n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(build_bias_segment_kernel, dim3((B * n + 255) / 256), dim3(256), 0, s, mask, bias, B, n, ld_bias, offset);
+    return hipGetLastError();
+}
+
 hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s) {
     int n = B * ld_bias;
     hipLaunchKernelGGL(build_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, bias, B, n_mask, ld_bias);

@@ -19,7 +19,7 @@ from typing import Any, Dict, Optional
 import torch
 
 from . import _hip
-from .configuration import DACConfig, GenerationConfig, ParlerTTSConfig
+from .configuration import DACConfig, GenerationConfig, ParlerTTSConfig, ParlerTTSDecoderConfig
 from .delay_pattern import apply_delay_pattern_mask, build_delay_pattern_mask
 from .weights import load_state_dict_from_dir, normalize_state_dict, synthetic_state_dict
 
@@ -186,11 +186,13 @@ class HipEngine:
         return codes
 
     def prefill(self, B, B_eff, enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, start_len,
-                prompt_embeds=None):
+                prompt_embeds=None, dec_mask=None):
         T = enc_states.shape[1]
         P = prompt_embeds.shape[1] if prompt_embeds is not None else (0 if prompt_ids is None else prompt_ids.shape[1])
         L = pattern.shape[1]
-        self._keep = (enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, prompt_embeds)  # raw pointers
+        self._keep = (enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, prompt_embeds, dec_mask)  # raw pointers
+        if dec_mask is not None:           # decoder_attention_mask over the prefix columns (M:845-846)
+            _hip.check(self.lib.ptts_set_decoder_mask(self.handle, _ptr(dec_mask)))
         if prompt_embeds is not None:      # pre-embedded prompts override the id lookup for this prefill (M:2476)
             _hip.check(self.lib.ptts_set_prompt_embeds(self.handle, _ptr(prompt_embeds)))
         _hip.check(self.lib.ptts_prefill(self.handle, B, B_eff, T, P, L, _ptr(enc_states), _ptr(attention_mask),
@@ -419,7 +421,8 @@ class ParlerTTSForConditionalGeneration:
             B_eff, T, P, L = max(B_eff, mb), max(T, mt), max(P, mp), max(L, ml)
         if self._sd is None:
             raise RuntimeError("no weights: construct with a state dict, from_pretrained() or from_synthetic()")
-        self._engine = HipEngine(self.config, self._sd, self.dtype, self.device, B_eff, T, P, L)
+        self._engine = HipEngine(self.config, self._sd, self.dtype, self.device, B_eff, T, P, L,
+                                 **getattr(self, "_engine_kw", {}))
         return self._engine
 
     # ---- generate ----
@@ -437,8 +440,9 @@ class ParlerTTSForConditionalGeneration:
         logits_processor = list(logits_processor) if logits_processor else []
         stopping_criteria = list(stopping_criteria) if stopping_criteria else []
         allowed = {"input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "encoder_outputs",
-                   "prompt_hidden_states", "decoder_input_ids", "return_raw_ids", "input_values", "padding_mask"}
-        unsupported = {"decoder_attention_mask"}
+                   "prompt_hidden_states", "decoder_input_ids", "return_raw_ids", "input_values", "padding_mask",
+                   "decoder_attention_mask"}
+        unsupported = set()
         for k in model_kwargs:
             if k in unsupported:
                 raise NotImplementedError(f"`{k}` is a SURVEY 8(f) 'next' row")
@@ -497,7 +501,21 @@ class ParlerTTSForConditionalGeneration:
             dec_in = dec_in.to(dev, torch.long)
             if dec_in.dim() != 2 or dec_in.shape[0] != B * K:
                 raise ValueError(f"decoder_input_ids must be [batch * num_codebooks = {B * K}, prefix_len], got {tuple(dec_in.shape)}")
-            ids = dec_in if not bool((dec_in[..., 0] != start_tok).all()) else torch.cat([ids, dec_in], dim=-1)
+            prepend = bool((dec_in[..., 0] != start_tok).all())
+            ids = dec_in if not prepend else torch.cat([ids, dec_in], dim=-1)
+        dec_mask = model_kwargs.get("decoder_attention_mask")
+        if dec_mask is not None:
+            # [B, prefix_len] over the prefix columns; a ones column joins a prepended start column (M:2186-2193).  The
+            # decoder concatenates it behind prompt_attention_mask (M:845-846); with a prompt but no prompt mask the
+            # reference's 4-D mask helper fails on the length mismatch (M:870-872), so that combination is rejected here.
+            dec_mask = dec_mask.to(dev)
+            if dec_in is not None and prepend:
+                dec_mask = torch.cat([torch.ones_like(dec_mask)[:, :1], dec_mask], dim=-1)
+            if dec_mask.dim() != 2 or dec_mask.shape[0] != B or dec_mask.shape[1] != ids.shape[1]:
+                raise ValueError(f"decoder_attention_mask must be [batch {B}, prefix_len {ids.shape[1]}], got {tuple(dec_mask.shape)}")
+            if P > 0 and prompt_mask is None:
+                raise ValueError("decoder_attention_mask with a prompt needs prompt_attention_mask as well: the reference "
+                                 "concatenates the two (M:845-846) and cannot build its causal mask from the shorter one")
         if gen.max_new_tokens is not None:
             gen.max_length = gen.max_new_tokens + ids.shape[-1]
         if gen.min_length is not None and gen.min_length > gen.max_length:
@@ -561,7 +579,11 @@ class ParlerTTSForConditionalGeneration:
         sp.guidance_scale = float(gen.guidance_scale) if use_cfg else 1.0
         sp.top_p = float(gen.top_p) if (gen.top_p is not None and 0.0 < gen.top_p < 1.0) else 1.0
         sp.seed = int(gen.seed if gen.seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len, prompt_embeds=pemb)
+        dmask32 = None
+        if dec_mask is not None:
+            dmask32 = dec_mask.to(torch.int32)
+            dmask32 = (dmask32.repeat(2, 1) if use_cfg else dmask32).contiguous()            # M:2112-2113
+        eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len, prompt_embeds=pemb, dec_mask=dmask32)
         t_dec = _tick()
         # ---- the hot loop: state lives on the device, the host only polls for "all rows finished" ----
         remaining = L - start_len
@@ -660,8 +682,102 @@ class ParlerTTSForConditionalGeneration:
 
 
 class ParlerTTSForCausalLM:
-    """The decoder-only driver (M:1281-1552) is outside the accelerated path."""
+    """Decoder-only driver with the reference's ``generate()`` contract (M:1281-1552): codec ids in, codec ids
+    ``[batch, num_codebooks, frames]`` out, conditioned on caller-supplied ``encoder_hidden_states`` (already in the decoder
+    width: the composite's ``enc_to_dec_proj`` is not part of this class) and optional ``prompt_hidden_states``.
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("ParlerTTSForCausalLM is not part of the MI355X generate() hot path; "
-                                  "use ParlerTTSForConditionalGeneration")
+    Same engine and kernels as the composite: the decoder state dict (``model.decoder.*``, ``lm_heads.*``; a composite
+    checkpoint's ``decoder.``-prefixed keys are accepted too) is loaded into a ``ptts_engine`` whose encoder width equals
+    the decoder width, so ``ptts_prefill`` skips the projection.  The reference multiplies nothing into
+    ``encoder_hidden_states`` here (M:1096-1185), the composite path multiplies by the mask (M:2016-2017); masked keys
+    carry weight exactly 0 in cross-attention either way, so the ids are the same.
+
+    Not served (raise): ``guidance_scale > 1`` (the reference doubles only the prompt here, M:1218-1232, and leaves the
+    encoder states to the caller) and calls without ``encoder_hidden_states`` (the engine always cross-attends)."""
+
+    config_class = ParlerTTSDecoderConfig
+
+    def __init__(self, config: ParlerTTSDecoderConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 dtype: str = "bf16", device="cuda:0", generation_config: Optional[GenerationConfig] = None):
+        from .configuration import T5EncoderConfig
+
+        _hip.load_library()
+        if state_dict is None:
+            raise RuntimeError("no weights: pass the decoder state dict (model.decoder.*, lm_heads.*)")
+        self.config = config
+        self.num_codebooks = config.num_codebooks
+        D = config.hidden_size
+        sd = {}
+        for k, v in state_dict.items():
+            if k.startswith("decoder."):
+                sd[k] = v
+            elif k.startswith(("model.decoder.", "lm_heads.")):
+                sd["decoder." + k] = v
+        pos = "decoder.model.decoder.embed_positions.weights"
+        if pos not in sd:
+            from .weights import sinusoid_table
+
+            sd[pos] = sinusoid_table(config.max_position_embeddings, D)
+        sd["embed_prompts.weight"] = torch.zeros(1, D)      # prompts arrive pre-embedded; the table is never indexed
+        wrap = ParlerTTSConfig.from_sub_models_config(T5EncoderConfig(d_model=D), DACConfig(num_codebooks=config.num_codebooks),
+                                                      config, vocab_size=1)
+        self._inner = ParlerTTSForConditionalGeneration(
+            wrap, sd, dtype=dtype, device=device,
+            generation_config=generation_config or GenerationConfig(
+                max_length=20, do_sample=False, guidance_scale=None, decoder_start_token_id=config.bos_token_id,
+                pad_token_id=config.pad_token_id, eos_token_id=config.eos_token_id, bos_token_id=config.bos_token_id))
+        self._inner._engine_kw = dict(with_t5=False)
+        self.generation_config = self._inner.generation_config
+        self.device = self._inner.device
+
+    def to(self, device):
+        self._inner.to(device)
+        self.device = self._inner.device
+        return self
+
+    def eval(self):
+        return self
+
+    def build_delay_pattern_mask(self, input_ids, bos_token_id, pad_token_id, max_length=None):
+        max_length = max_length if max_length is not None else self.generation_config.max_length      # M:1265-1266
+        return build_delay_pattern_mask(input_ids, bos_token_id, pad_token_id, max_length, self.num_codebooks)
+
+    @staticmethod
+    def apply_delay_pattern_mask(input_ids, decoder_pad_token_mask):
+        return apply_delay_pattern_mask(input_ids, decoder_pad_token_mask)
+
+    @torch.no_grad()
+    def generate(self, inputs: Optional[torch.Tensor] = None, generation_config: Optional[GenerationConfig] = None,
+                 logits_processor=None, stopping_criteria=None, synced_gpus: Optional[bool] = None, streamer=None,
+                 **kwargs):
+        """M:1281-1552.  ``inputs`` / ``input_ids``: decoder ids ``[batch * num_codebooks, s]`` (default: one BOS column,
+        which then needs ``batch_size`` from ``encoder_hidden_states``); ``attention_mask``: ``[batch, s]`` over those
+        columns; ``encoder_hidden_states`` ``[batch, T, hidden]`` + ``encoder_attention_mask``; ``prompt_hidden_states``
+        ``[batch, P, hidden]`` + ``prompt_attention_mask``.  Returns the un-delayed ids ``[batch, num_codebooks, frames]``
+        (M:1532-1546)."""
+        kwargs = dict(kwargs)
+        gs = kwargs.get("guidance_scale", (generation_config or self.generation_config).guidance_scale)
+        if gs is not None and gs > 1:
+            raise NotImplementedError("guidance_scale > 1 on the decoder-only driver: the reference doubles only the prompt "
+                                      "(M:1218-1232); use ParlerTTSForConditionalGeneration for classifier-free guidance")
+        enc = kwargs.pop("encoder_hidden_states", None)
+        if enc is None:
+            raise ValueError("ParlerTTSForCausalLM.generate needs `encoder_hidden_states` [batch, T, hidden]")
+        if enc.dim() != 3 or enc.shape[-1] != self.config.hidden_size:
+            raise ValueError(f"encoder_hidden_states must be [batch, T, {self.config.hidden_size}], got {tuple(enc.shape)}")
+        ids = inputs if inputs is not None else kwargs.pop("input_ids", None)
+        kwargs.pop("input_ids", None)
+        inner = dict(encoder_outputs=(enc,), attention_mask=kwargs.pop("encoder_attention_mask", None), return_raw_ids=True)
+        if ids is not None:
+            inner["decoder_input_ids"] = ids
+        dmask = kwargs.pop("attention_mask", None)
+        if dmask is not None:
+            inner["decoder_attention_mask"] = dmask
+        out = self._inner.generate(generation_config=generation_config, logits_processor=logits_processor,
+                                   stopping_criteria=stopping_criteria, synced_gpus=synced_gpus, streamer=streamer,
+                                   **inner, **kwargs)
+        self.last_raw_ids = self._inner.last_raw_ids
+        codes = out[0]                                   # [B, K, F]
+        if (generation_config or self.generation_config).return_dict_in_generate or kwargs.get("return_dict_in_generate"):
+            return ModelOutput(sequences=codes)
+        return codes

@@ -1020,6 +1020,69 @@ def test_decoder_input_ids_prefix(hip):
         model.generate(decoder_input_ids=prefix[:-1], **kw)
 
 
+@pytest.mark.parametrize("name", ["tiny_prefix", "tiny_prefix_masked"])
+def test_decoder_prefix_fixtures_from_the_reference(hip, name):
+    """Fixtures written by the REAL reference forward with `decoder_input_ids` and, in the masked case, a left-padded
+    `decoder_attention_mask` + ragged prompt / description masks (M:845-846, M:2150-2195): fp32 engine ids bit-exact."""
+    f, meta = load_case(name)
+    cfg, model = model_for(name, meta, "fp32")
+    desc, amask, prompt, pmask = case_inputs(f)
+    prefix = torch.from_numpy(f["decoder_input_ids"])
+    dmask = torch.from_numpy(f["decoder_attention_mask"]) if "decoder_attention_mask" in f else None
+    enc = torch.from_numpy(f["enc_t5"])
+    kw = dict(encoder_outputs=(enc,), attention_mask=amask, prompt_input_ids=prompt, prompt_attention_mask=pmask,
+              do_sample=False, max_length=int(f["max_length"]), return_raw_ids=True, decoder_input_ids=prefix)
+    if dmask is not None:
+        kw["decoder_attention_mask"] = dmask
+    got = model.generate(**kw)
+    start_len = prefix.shape[1] + 1
+    free = torch.from_numpy(f["pattern"][:, start_len:] == -1)
+    raw = model.last_raw_ids.cpu()
+    assert torch.equal(raw[:, start_len:][free], torch.from_numpy(f["raw_ids"])[:, start_len:][free])
+    assert torch.equal(got.cpu()[0], torch.from_numpy(f["codes"]))
+    if dmask is not None:
+        # the mask matters: without it the padded prefix columns are attended and the ids change
+        kw.pop("decoder_attention_mask")
+        other = model.generate(**kw)
+        assert not torch.equal(other, got)
+        # a decoder mask next to a prompt needs the prompt mask too (the reference cannot build its causal mask otherwise)
+        with pytest.raises(ValueError):
+            model.generate(**{**kw, "decoder_attention_mask": dmask, "prompt_attention_mask": None})
+        # under classifier-free guidance the mask is repeated with the rows (M:2112-2113): runs and stays finite
+        g = model.generate(**{**kw, "decoder_attention_mask": dmask, "guidance_scale": 2.0})
+        assert g.shape == got.shape
+
+
+def test_decoder_only_driver(hip):
+    """ParlerTTSForCausalLM.generate (M:1281-1552) against the fixture the REAL class produced: encoder and prompt hidden
+    states handed in directly (ragged masks), decoder-only state dict (model.decoder.*, lm_heads.*), ids bit-exact."""
+    from parler_tts_amd.modeling import ParlerTTSForCausalLM
+
+    f, meta = load_case("tiny_causal")
+    cfg, sd = state_dict_for("tiny_causal", meta)
+    dec_sd = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+    assert any(k.startswith("lm_heads.") for k in dec_sd) and any(k.startswith("model.decoder.layers.") for k in dec_sd)
+    _models.clear()
+    model = ParlerTTSForCausalLM(cfg.decoder, dec_sd, dtype="fp32", device="cuda:0")
+    t = lambda k: torch.from_numpy(f[k])
+    kw = dict(encoder_hidden_states=t("enc_h"), encoder_attention_mask=t("emask"), prompt_hidden_states=t("prompt_h"),
+              prompt_attention_mask=t("pmask"), do_sample=False, max_length=int(f["max_length"]))
+    codes = model.generate(**kw)
+    assert torch.equal(codes.cpu(), t("codes"))
+    free = torch.from_numpy(f["pattern"][:, 1:] == -1)
+    assert torch.equal(model.last_raw_ids.cpu()[:, 1:][free], t("raw_ids")[:, 1:][free])
+    # explicit BOS column == default start; errors of the driver
+    K = cfg.decoder.num_codebooks
+    again = model.generate(torch.full((3 * K, 1), cfg.decoder.bos_token_id), **kw)
+    assert torch.equal(again, codes)
+    with pytest.raises(ValueError):
+        model.generate(do_sample=False, max_length=24)
+    with pytest.raises(NotImplementedError):
+        model.generate(guidance_scale=3.0, **kw)
+    with pytest.raises(ValueError):
+        model.generate(num_beams=2, **kw)
+
+
 def test_lookahead_cross_q_two_m_tiles_bf16(hip):
     """Look-ahead cross-q with more than one 32-row m-tile (batch 40; the same layout guidance gives at batch 32):
     teacher-forced logits of the mini_v0.1 decoder, look-ahead on vs off."""

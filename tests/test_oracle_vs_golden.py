@@ -74,6 +74,43 @@ def test_decoder_loop_matches_reference(name):
     assert codes.shape[-1] == frames_kept(r["raw_ids"].shape[1], cfg.decoder.num_codebooks)
 
 
+@pytest.mark.parametrize("name", ["tiny_prefix", "tiny_prefix_masked"])
+def test_decoder_prefix_and_decoder_attention_mask_match_reference(name):
+    """`decoder_input_ids` (M:2150-2195) and `decoder_attention_mask` (M:845-846; left-padded prefix rows) through the real
+    reference forward: the restated loop reproduces its logits and ids."""
+    f, meta = load_case(name)
+    cfg, sd = state_dict_for(name, meta)
+    desc, amask, prompt, pmask = case_inputs(f)
+    prefix = torch.from_numpy(f["decoder_input_ids"])
+    dmask = torch.from_numpy(f["decoder_attention_mask"]) if "decoder_attention_mask" in f else None
+    assert (dmask is not None) == name.endswith("masked")
+    r = cpu_ref.generate_ids(cfg, sd, torch.from_numpy(f["enc_t5"]), amask, prompt, pmask, int(f["max_length"]),
+                             record_logits=f["step_logits"].shape[0], decoder_input_ids=prefix, decoder_attention_mask=dmask)
+    assert np.abs(r["step_logits"].numpy() - f["step_logits"]).max() < 2e-5
+    assert np.array_equal(r["pattern"].numpy(), f["pattern"])
+    assert r["raw_ids"].shape == f["raw_ids"].shape
+    start_len = prefix.shape[1] + 1
+    free = f["pattern"][:, start_len:] == -1
+    assert np.array_equal(r["raw_ids"].numpy()[:, start_len:][free], f["raw_ids"][:, start_len:][free])
+    # every kept argmax of the reference run is far from a tie (step j fills column start_len + j)
+    m = f["margins"]
+    assert float(m[free.T[: m.shape[0]]].min()) >= 1e-3
+    assert np.array_equal(cpu_ref.undelay(cfg, r["raw_ids"], r["pattern"])[0].numpy(), f["codes"])
+
+
+def test_decoder_only_driver_matches_reference():
+    """ParlerTTSForCausalLM.generate (M:1281-1552) on the real class: encoder / prompt hidden states handed in directly."""
+    f, meta = load_case("tiny_causal")
+    cfg, sd = state_dict_for("tiny_causal", meta)
+    t = lambda k: torch.from_numpy(f[k])
+    r = cpu_ref.generate_ids(cfg, sd, t("enc_h"), t("emask"), None, t("pmask"), int(f["max_length"]), record_logits=64,
+                             prompt_hidden_states=t("prompt_h"), decoder_only=True)
+    assert np.abs(r["step_logits"].numpy() - f["step_logits"]).max() < 2e-5
+    assert np.array_equal(r["raw_ids"].numpy(), f["raw_ids"])
+    assert np.array_equal(cpu_ref.undelay(cfg, r["raw_ids"], r["pattern"])[0].numpy(), f["codes"])
+    assert float(f["free_min_margin"]) >= 1e-3
+
+
 def test_static_kv_equals_cat_kv():
     f, meta = load_case("tiny_greedy")
     cfg, sd = state_dict_for("tiny_greedy", meta)
