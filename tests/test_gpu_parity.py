@@ -711,8 +711,9 @@ def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
 # ------------------------------------------------------------------------------------------------
 # shapes beyond the fixtures: more than one 32-row m-tile, and BASELINE configs[4] (scaled decoder)
 # ------------------------------------------------------------------------------------------------
-def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps):
-    """teacher-forced along the ORACLE's greedy path; returns (engine logits, oracle logits, oracle ids)"""
+def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, check_t5=False):
+    """teacher-forced along the ORACLE's greedy path; returns (engine logits, oracle logits, oracle ids).
+    ragged: right-padded descriptions and LEFT-padded prompts (training script T:916) with their masks."""
     from oracle import cpu_ref
     from parler_tts_amd import _hip
     from parler_tts_amd.delay_pattern import build_delay_pattern_mask
@@ -722,8 +723,14 @@ def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps):
     desc = torch.randint(2, cfg.text_encoder.vocab_size, (B, T), generator=g)
     prompt = torch.randint(2, cfg.vocab_size, (B, P), generator=g)
     amask = torch.ones(B, T, dtype=torch.long)
+    pmask = None
+    if ragged:
+        pmask = torch.ones(B, P, dtype=torch.long)
+        for b in range(1, B):
+            amask[b, T - (7 * b) % (T // 2):] = 0
+            pmask[b, : (5 * b) % (P // 2 + 1)] = 0
     enc = cpu_ref.t5_encode(cfg, sd, desc, amask)
-    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, None, L, record_logits=steps)
+    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, record_logits=steps)
     _models.clear()
     torch.cuda.empty_cache()
     model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=dtype, device="cuda:0")
@@ -735,8 +742,11 @@ def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps):
     pattern = pattern.to(dev).contiguous()
     raw = torch.full((B * K, L), cfg.decoder.pad_token_id, dtype=torch.long, device=dev)
     raw[:, :1] = ids.to(dev)
-    eng.prefill(B, B, enc.to(dev).contiguous(), amask.to(dev, torch.int32).contiguous(), prompt.to(dev).contiguous(), None,
-                pattern, raw, 1)
+    if check_t5:       # the HIP T5 encoder at this length, valid rows only (padded rows are never attended)
+        enc_gpu = eng.t5_encode(desc.to(dev), amask.to(dev)).cpu()
+        assert ((enc_gpu - enc).abs() * amask[..., None]).max() < 2e-4
+    eng.prefill(B, B, enc.to(dev).contiguous(), amask.to(dev, torch.int32).contiguous(), prompt.to(dev).contiguous(),
+                None if pmask is None else pmask.to(dev, torch.int32).contiguous(), pattern, raw, 1)
     sp = _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
     out = []
     for s in range(steps):
@@ -763,6 +773,38 @@ def test_two_m_tiles_batch_40_fp32(hip):
     top2 = torch.topk(want, 2, dim=-1)[0]
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3            # only argmaxes the reference itself decides clearly
     assert torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe])
+
+
+def test_long_description_long_prompt_and_page_crossings_fp32(hip):
+    """Lengths the fixtures never reach: a description of 90 tokens (cross-attention over two KV pages on the general
+    kernel, T5 over 90 positions), a left-padded prompt of 70 tokens (prefill crosses a page), 60 generated columns (self
+    KV positions up to 129: three pages), ragged masks; fp32 engine teacher-forced along the oracle's greedy path."""
+    from parler_tts_amd.configuration import tiny_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=11, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+    got, want, ref_ids, got_raw = _oracle_vs_engine(cfg, sd, "fp32", B=3, T=90, P=70, L=61, seed=8, steps=60, ragged=True,
+                                                    check_t5=True)
+    assert (got - want).abs().max() < 2e-4
+    top2 = torch.topk(want, 2, dim=-1)[0]
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+    assert torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe])
+
+
+def test_long_description_bf16_lookahead_off_path(hip):
+    """bf16 engine with a description longer than one KV page: the look-ahead cross-q is inactive (it rides on the
+    single-page cross-attention kernel) and the folded LayerNorm feeds the separate cross-q projection instead."""
+    from parler_tts_amd.configuration import tiny_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=11, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+    got, want, _, _ = _oracle_vs_engine(cfg, sd, "bf16", B=3, T=90, P=70, L=41, seed=9, steps=40, ragged=True)
+    assert (got - want).abs().max() < 0.08
+    top2 = torch.topk(want, 2, dim=-1)[0]
+    safe = (top2[..., 0] - top2[..., 1]) > 0.05
+    assert (got.argmax(-1)[safe] == want.argmax(-1)[safe]).float().mean() > 0.9
 
 
 def test_scaled_decoder_config_bf16(hip):
