@@ -23,7 +23,11 @@ struct AttnArgs {
     int lnfix_blocks = 0;                // 16-column blocks per row (K / 16)
     const float* lnfix_c1 = nullptr;
     const float* lnfix_c2 = nullptr;
-    float lnfix_eps = 1e-5f, lnfix_scale = 1.0f;       // 1: always use the general kernel (A/B and equivalence tests)
+    float lnfix_eps = 1e-5f, lnfix_scale = 1.0f;
+    // general kernel, self-attention only (len_from_state): `q` holds the RAW look-ahead product [q | k | v] (ldq = 3 D) of the
+    // folded QKV projection; the kernel finishes the LayerNorm of its head's three 64-wide slices (c1 / c2 are [3 D]), scales
+    // q, and appends the k / v rows to the cache at state->pos itself before it streams the cache
+    int lnfix_qkv = 0;       // 1: always use the general kernel (A/B and equivalence tests)
 };
 
 struct FullAttnArgs {

@@ -74,18 +74,47 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
 
     float q[EPL];
-    {
-        const float* qp = a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) q[j] = qp[j];
-    }
     const float* bias = a.bias ? a.bias + (size_t)b * a.ld_bias : nullptr;
     // page ids once into LDS: KV addresses then depend on no global load
     for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[b * a.pool.max_blocks + i];
-    __syncthreads();
     const size_t page_elems = a.pool.page_elems();       // stride between two pages inside this head's K (or V) slab
     const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
+    if (a.lnfix_qkv) {
+        // Look-ahead QKV: `a.q` is the raw product x.Wqkv'^T this head's slices of which still need the LayerNorm of the
+        // folded projection, rstd * (raw - mean * c1) + c2, from the per-block statistics the producing launch wrote.
+        // Waves 0..2 take q, k, v (64 values each): q goes to LDS (scaled), k and v are appended to the cache at
+        // position S - 1; the barrier below (a workgroup-scope fence for global memory) orders the append before the
+        // streamed read of that row, which sits in the last tile of the stream.
+        float* qs = reinterpret_cast<float*>(pages + a.pool.max_blocks);          // [64]
+        if (w < 3) {
+            const float* sp = a.lnfix_stat + ((size_t)(b >> 5) * a.lnfix_blocks * 32 + (b & 31)) * 2;
+            float st_s = 0.f, st_q = 0.f;
+            for (int nbk = lane; nbk < a.lnfix_blocks; nbk += 64) {
+                st_s += sp[(size_t)nbk * 64];
+                st_q += sp[(size_t)nbk * 64 + 1];
+            }
+            const float Kf = (float)(a.lnfix_blocks * 16);
+            const float mean = wave_sum(st_s) / Kf;
+            const float var = fmaxf(wave_sum(st_q) / Kf - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + a.lnfix_eps);
+            const int n = w * a.D + h * PTTS_HEAD_DIM + lane;
+            const float y = rstd * (a.q[(size_t)b * a.ldq + n] - mean * a.lnfix_c1[n]) + a.lnfix_c2[n];
+            if (w == 0) qs[lane] = y * a.lnfix_scale;
+            else {
+                elem_t* dst = const_cast<elem_t*>(pool) + a.pool.elem_off(b, a.layer, w - 1, h, S - 1) + lane;
+                *dst = to_elem<P>(y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) q[j] = qs[c * EPL + j];
+    } else {
+        const float* qp = a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) q[j] = qp[j];
+        __syncthreads();
+    }
     const int ntiles = (S + TPW - 1) / TPW;
 
     // one burst = UNR tiles of 1 KiB, all issued before the first use (plain loads: hipcc counts them)
@@ -433,7 +462,7 @@ hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, 
         }
         return hipGetLastError();
     }
-    size_t lds = ((size_t)a.s_cap + NWAVES * 64 + NWAVES + a.pool.max_blocks) * sizeof(float);
+    size_t lds = ((size_t)a.s_cap + NWAVES * 64 + NWAVES + a.pool.max_blocks + 64) * sizeof(float);   // + 64: look-ahead q
     dim3 grid(H, B), block(NWAVES * 64);
 #define PTTS_ATTN_LAUNCH(P_, O_)                                                                             \
     do {                                                                                                     \

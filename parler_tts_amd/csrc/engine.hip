@@ -64,6 +64,7 @@ struct DecLayer {
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
     Folded qkv_f, cq_f, fc1_f;
     void* look = nullptr;      // look-ahead weights [D][2D]: [cq_f.w | cq_f.w . o]  (see run_layers)
+    void* look2 = nullptr;     // look-ahead QKV of the NEXT layer [3D][D+F]: [qkv_f.w(l+1) | qkv_f.w(l+1) . fc2(l)]
 };
 struct T5Layer {
     Packed qkv, o, wi, wo;
@@ -102,6 +103,9 @@ struct ptts_engine {
     int fold_mask = 15;
     bool lookahead = false;    // cross-q computed inside the self-attention out-projection launch (default with the fold)
     bool look_active = false;  // ... and usable for the current call (single-page description, fold on)
+    bool lookahead2 = false;   // QKV of layer l+1 computed inside layer l's fc2 launch (PTTS_LOOKAHEAD2=1; off by default: slower)
+    bool look2_active = false;
+    float* qkv_raw = nullptr;  // [rows][3D] raw look-ahead QKV product
     void* x_frag2 = nullptr;   // second fragment buffer (the out-projection reads the old rows while writing the new)
     void* xf_cur = nullptr;    // fragment buffer that holds the current residual rows
     float* xstat = nullptr;    // per-block row statistics of the rows the out-projection wrote
@@ -291,7 +295,15 @@ int refresh_folds(ptts_engine* e, hipStream_t s) {
         if (e->lookahead) {
             const int D = e->cfg.hidden;
             if (!w.look) PTTS_TRY(dev_alloc(e, &w.look, (size_t)D * 2 * D * e->esz));
-            HIP_TRY(lookahead_build_launch(w.cq_f.w, w.o.ptr, w.look, D, D, e->dt, s));
+            HIP_TRY(lookahead_build_launch(w.cq_f.w, w.o.ptr, w.look, D, D, D, e->dt, s));
+        }
+    }
+    if (e->lookahead2) {   // needs the NEXT layer's folded QKV: after the loop above
+        const int D = e->cfg.hidden, F = e->cfg.ffn;
+        for (size_t l = 0; l + 1 < e->layers.size(); ++l) {
+            DecLayer& w = e->layers[l];
+            if (!w.look2) PTTS_TRY(dev_alloc(e, &w.look2, (size_t)3 * D * (D + F) * e->esz));
+            HIP_TRY(lookahead_build_launch(e->layers[l + 1].qkv_f.w, w.fc2.ptr, w.look2, 3 * D, D, F, e->dt, s));
         }
     }
     PTTS_TRY(fold_one(e, e->heads, e->lnf_g, e->lnf_b, &e->heads_f, s));
@@ -308,19 +320,28 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         DecLayer& w = e->layers[l];
         GemmArgs g;
         // LN1 + fused QKV projection; q scaled (M:282), k/v appended to the paged cache (M:299-304)
-        g = GemmArgs();
-        g.W = w.qkv.ptr; g.N = 3 * D; g.K = D; g.M = M;
-        g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.eps = 1e-5f;
-        use_fold(e, &g, w.qkv_f, 0);
-        g.epi = EPI_QKV_SELF; g.out = e->q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
-        g.state = e->state; g.D = D;
-        DBG_GATE(e);
-        PTTS_TRY(launch_gemm(e, g, s));
+        // Look-ahead QKV (layers behind the first): the raw product x.Wqkv'^T was computed by the previous layer's fc2 launch
+        // (second role, below); the self-attention kernel finishes the LayerNorm, scales q and appends k / v itself.
+        const bool pre_qkv = e->look2_active && l > 0;
+        if (!pre_qkv) {
+            g = GemmArgs();
+            g.W = w.qkv.ptr; g.N = 3 * D; g.K = D; g.M = M;
+            g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.eps = 1e-5f;
+            use_fold(e, &g, w.qkv_f, 0);
+            g.epi = EPI_QKV_SELF; g.out = e->q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
+            g.state = e->state; g.D = D;
+            DBG_GATE(e);
+            PTTS_TRY(launch_gemm(e, g, s));
+        }
         // self attention over pos+1 cached tokens
         AttnArgs a;
         a.q = e->q; a.ldq = D; a.pool = make_pool(e, false); a.layer = l; a.len_from_state = 1; a.state = e->state;
         a.bias = e->has_self_bias ? e->self_bias : nullptr; a.ld_bias = e->s_cap; a.s_cap = e->s_cap;
         a.ofrag = e->attn_frag; a.D = D;
+        if (pre_qkv) {
+            a.q = e->qkv_raw; a.ldq = 3 * D; a.lnfix_qkv = 1; a.lnfix_stat = e->xstat; a.lnfix_blocks = D / 16;
+            a.lnfix_c1 = w.qkv_f.c1; a.lnfix_c2 = w.qkv_f.c2; a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
+        }
         EventPair* ep = nullptr;
         if (profile && e->ev_used < e->ev_pool.size()) {
             ep = &e->ev_pool[e->ev_used++];
@@ -385,6 +406,15 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         g = GemmArgs();
         g.W = w.fc2.ptr; g.N = D; g.K = F; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->mlp_frag;
         g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
+        if (e->look2_active && l + 1 < c.layers) {
+            // look-ahead QKV of layer l+1: LN1(x + g.W2^T).Wqkv^T = rstd * ((x.Wqkv'^T + g.(Wqkv'.W2)^T) - mean * c1) + c2;
+            // extra workgroups of this launch compute the raw product from the rows it starts from (x fragments) and its
+            // own input (GELU fragments); the new rows go to the other fragment buffer, their statistics to `xstat`
+            void* next = e->xf_cur == e->x_frag ? e->x_frag2 : e->x_frag;
+            g.W2 = w.look2; g.N2 = 3 * D; g.K2 = D + F; g.xfrag_lo = e->xf_cur; g.ksplit = D / (e->dt == PTTS_DTYPE_BF16 ? 32 : 16);
+            g.out2 = e->qkv_raw; g.ldo2 = 3 * D; g.xfrag_out = next; g.xstat = e->xstat;
+            e->xf_cur = next;
+        }
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
     }
@@ -699,6 +729,10 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->no_page_kernel = getenv("PTTS_ATTN_NO_PAGE_KERNEL") != nullptr;
     e->lookahead = e->fold_ln;      // look-ahead cross-q rides on the folded LayerNorm (PTTS_LOOKAHEAD=0 switches it off)
     if (const char* v = getenv("PTTS_LOOKAHEAD")) e->lookahead = atoi(v) != 0;
+    // look-ahead QKV: correct (parity tests) but SLOWER than the separate launch on this part (decode pass +6.7 %: the
+    // product weights add 25 MB per layer to the fc2 launch), so it is an experiment switch only (PTTS_LOOKAHEAD2=1)
+    e->lookahead2 = false;
+    if (const char* v = getenv("PTTS_LOOKAHEAD2")) e->lookahead2 = atoi(v) != 0 && e->fold_ln;
     if (const char* v = getenv("PTTS_FOLD_MASK")) e->fold_mask = atoi(v);
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     if (cfg->dac_hidden > 0) {
@@ -780,6 +814,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->x_frag, e->esz * rows * D);
     A(e->x_frag2, e->esz * rows * D);
     A(e->xstat, sizeof(float) * 2 * rows * (D / 16 + 1));
+    A(e->qkv_raw, sizeof(float) * rows * 3 * D);
     A(e->mlp_frag, e->esz * rows * F);
     A(e->logits, sizeof(float) * rows * K * e->Vp);
     A(e->probs, sizeof(float) * rows * K * e->Vp);
@@ -1016,6 +1051,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     e->B = B; e->B_eff = B_eff; e->T = T; e->P = P; e->L = L;
     // the look-ahead query needs the folded projection, the single-page cross-attention kernel and bf16-size k-steps
     e->look_active = e->lookahead && e->fold_ln && (e->fold_mask & 2) && !e->no_page_kernel && T <= PTTS_PAGE_TOKENS;
+    e->look2_active = e->lookahead2 && e->fold_ln && (e->fold_mask & 1);
     e->pattern = (const long long*)pattern; e->raw_ids = (long long*)raw_ids; e->prompt_ids = (const long long*)prompt_ids;
     const int D = c.hidden, M = B_eff * T;
     // additive masks (M:870-879)

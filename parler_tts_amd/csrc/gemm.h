@@ -66,7 +66,8 @@ hipError_t fold_layernorm_launch(const void* W, void* Wf, const float* gamma, co
 hipError_t rows_to_frag_launch(const float* X, void* xfrag, int M, int K, int dtype, hipStream_t stream);
 // look-ahead weights (packed [N][2K]): columns 0..K-1 = Wf (the gamma-folded projection, packed [N][K]); columns K..2K-1 =
 // Wf . Wo, Wo packed [K][K] = the residual projection whose output the folded projection would have read
-hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int N, int K, int dtype, hipStream_t stream);
+// out [N][K1 + K2] = [Wf | Wf . Wo] with Wf [N][K1], Wo [K1][K2], all in packed tile order
+hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int N, int K1, int K2, int dtype, hipStream_t stream);
 // number of elements of `a` that differ bitwise from `b`; *first = linear index of one of them (diagnostics)
 hipError_t compare_launch(const float* a, const float* b, size_t n, unsigned* count, unsigned* first, hipStream_t stream);
 hipError_t convert_launch(const float* src, void* dst, size_t n, int dtype, hipStream_t stream);

@@ -609,21 +609,22 @@ __global__ __launch_bounds__(64) void fold_ln_kernel(const typename P::elem_t* _
     }
 }
 
-// one block = one output row n and 256 consecutive columns of the stacked matrix (runs once per weight set)
+// one block = one output row n and 256 consecutive columns of the stacked matrix [Wf | Wf . Wo] (runs once per weight set):
+// Wf [N][K1] (packed, K = K1), Wo [K1][K2] (packed, K = K2), out [N][K1 + K2] (packed, K = K1 + K2)
 template <typename P>
 __global__ __launch_bounds__(256) void lookahead_build_kernel(const typename P::elem_t* __restrict__ Wf,
                                                               const typename P::elem_t* __restrict__ Wo,
-                                                              typename P::elem_t* __restrict__ out, int N, int K) {
+                                                              typename P::elem_t* __restrict__ out, int N, int K1, int K2) {
     const int n = blockIdx.y, jj = blockIdx.x * 256 + threadIdx.x;
-    if (jj >= 2 * K) return;
-    if (jj < K) {
-        out[wpack_off<P>(n, jj, 2 * K)] = Wf[wpack_off<P>(n, jj, K)];
+    if (jj >= K1 + K2) return;
+    if (jj < K1) {
+        out[wpack_off<P>(n, jj, K1 + K2)] = Wf[wpack_off<P>(n, jj, K1)];
         return;
     }
-    const int j = jj - K;
+    const int j = jj - K1;
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(from_elem<P>(Wf[wpack_off<P>(n, k, K)]), from_elem<P>(Wo[wpack_off<P>(k, j, K)]), acc);
-    out[wpack_off<P>(n, jj, 2 * K)] = to_elem<P>(acc);
+    for (int k = 0; k < K1; ++k) acc = fmaf(from_elem<P>(Wf[wpack_off<P>(n, k, K1)]), from_elem<P>(Wo[wpack_off<P>(k, j, K2)]), acc);
+    out[wpack_off<P>(n, jj, K1 + K2)] = to_elem<P>(acc);
 }
 
 __global__ void compare_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, unsigned* count, unsigned* first) {
@@ -707,14 +708,14 @@ hipError_t fold_layernorm_launch(const void* W, void* Wf, const float* gamma, co
     return hipGetLastError();
 }
 
-hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int N, int K, int dtype, hipStream_t stream) {
-    dim3 grid((2 * K + 255) / 256, N);
+hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int N, int K1, int K2, int dtype, hipStream_t stream) {
+    dim3 grid((K1 + K2 + 255) / 256, N);
     if (dtype == PTTS_BF16)
         hipLaunchKernelGGL(lookahead_build_kernel<PBF16>, grid, dim3(256), 0, stream, (const uint16_t*)Wf, (const uint16_t*)Wo,
-                           (uint16_t*)out, N, K);
+                           (uint16_t*)out, N, K1, K2);
     else
         hipLaunchKernelGGL(lookahead_build_kernel<PF32>, grid, dim3(256), 0, stream, (const float*)Wf, (const float*)Wo,
-                           (float*)out, N, K);
+                           (float*)out, N, K1, K2);
     return hipGetLastError();
 }
 

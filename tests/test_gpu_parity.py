@@ -1030,6 +1030,21 @@ def test_lookahead_cross_q_agrees_with_separate_projection(hip):
     assert (a - b).abs().max().item() < 1e-4
 
 
+def test_lookahead_qkv_agrees_with_separate_projection(hip):
+    """Look-ahead QKV (layer l+1's x.Wqkv' + g.(Wqkv'.W2) inside layer l's fc2 launch; the self-attention kernel finishes
+    the LayerNorm from per-block statistics, scales q and appends k / v) vs the separate folded QKV launch: same model,
+    same teacher-forced tokens; ragged masks and guidance rows included; the fp32 engine with the fold on as a tight check."""
+    for name in ("tiny_greedy", "tiny_greedy_ragged", "tiny_cfg"):
+        a = _fresh_engine_logits(name, "bf16", {"PTTS_LOOKAHEAD2": "1"})
+        b = _fresh_engine_logits(name, "bf16", {"PTTS_LOOKAHEAD2": "0"})
+        assert not torch.isnan(a).any()
+        assert (a - b).abs().max().item() < 0.05, name
+        assert (a.argmax(-1) == b.argmax(-1)).float().mean().item() > 0.95, name
+    a = _fresh_engine_logits("tiny_greedy", "fp32", {"PTTS_LOOKAHEAD2": "1", "PTTS_LN_FOLD": "1"})
+    b = _fresh_engine_logits("tiny_greedy", "fp32", {"PTTS_LOOKAHEAD2": "0", "PTTS_LN_FOLD": "1"})
+    assert (a - b).abs().max().item() < 1e-4
+
+
 def test_decoder_input_ids_prefix(hip):
     """User `decoder_input_ids` (M:2150-2195): the prefix is delay-shifted by build_delay_pattern_mask (M:108-111), passes
     through the cache teacher-forced, and generation continues after it.  fp32 engine vs the oracle loop, bit-exact."""
