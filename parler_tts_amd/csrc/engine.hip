@@ -105,6 +105,7 @@ struct ptts_engine {
     bool look_active = false;  // ... and usable for the current call (single-page description, fold on)
     bool lookahead2 = false;   // QKV of layer l+1 computed inside layer l's fc2 launch (PTTS_LOOKAHEAD2=1; off by default: slower)
     bool look2_active = false;
+    bool look2_wide = true;    // 32-row workgroups for the fused fc2 + look-ahead QKV launch (PTTS_LOOKAHEAD2_WIDE=0: half-split grid)
     float* qkv_raw = nullptr;  // [rows][3D] raw look-ahead QKV product
     void* x_frag2 = nullptr;   // second fragment buffer (the out-projection reads the old rows while writing the new)
     void* xf_cur = nullptr;    // fragment buffer that holds the current residual rows
@@ -413,6 +414,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
             void* next = e->xf_cur == e->x_frag ? e->x_frag2 : e->x_frag;
             g.W2 = w.look2; g.N2 = 3 * D; g.K2 = D + F; g.xfrag_lo = e->xf_cur; g.ksplit = D / (e->dt == PTTS_DTYPE_BF16 ? 32 : 16);
             g.out2 = e->qkv_raw; g.ldo2 = 3 * D; g.xfrag_out = next; g.xstat = e->xstat;
+            g.wide2 = e->look2_wide ? 1 : 0;
             e->xf_cur = next;
         }
         DBG_GATE(e);
@@ -733,6 +735,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     // product weights add 25 MB per layer to the fc2 launch), so it is an experiment switch only (PTTS_LOOKAHEAD2=1)
     e->lookahead2 = false;
     if (const char* v = getenv("PTTS_LOOKAHEAD2")) e->lookahead2 = atoi(v) != 0 && e->fold_ln;
+    if (const char* v = getenv("PTTS_LOOKAHEAD2_WIDE")) e->look2_wide = atoi(v) != 0;
     if (const char* v = getenv("PTTS_FOLD_MASK")) e->fold_mask = atoi(v);
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     if (cfg->dac_hidden > 0) {

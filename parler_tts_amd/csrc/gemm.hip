@@ -203,6 +203,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         nb0 = (((id >> 4) << 3) + (id & 7)) * NB;
         hsel = (id >> 3) & 1;
         if (nb0 * 16 >= a.N) return;            // padding blocks of the last group of 8
+    } else if (!STAGE && !FOLD && a.W2) {       // wide second role: 32-row workgroups, the look-ahead blocks follow the first role's
+        const int ids1 = a.N / (16 * NB);
+        if ((int)blockIdx.x >= ids1) {
+            role2 = true;
+            nb0 = ((int)blockIdx.x - ids1) * NB;
+            a.W = a.W2; a.N = a.N2; a.K = a.K2;
+            a.epi = EPI_ROWMAJOR; a.out = a.out2; a.ldo = a.ldo2;
+            a.bias = nullptr; a.rowmask = nullptr; a.act = ACT_NONE; a.xfrag_out = nullptr; a.xstat = nullptr;
+        }
     }
     const int m0 = blockIdx.y * 32;
     const int K = a.K;
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         }
         const int n = gated ? blockIdx.x * 16 + 4 * (ln >> 4) : (nb0 + i) * 16 + 4 * (ln >> 4);
         if (row < a.M) epilogue<P>(a, row, n, s, s1, xres, have_res && t == tid);
-        if (H2 == 1 && !STAGE && !FOLD && a.xstat && a.epi == EPI_RESIDUAL) {
+        if (!STAGE && !FOLD && a.xstat && a.epi == EPI_RESIDUAL) {
             // partial LayerNorm statistics of the rows just written, over this block's 16 columns, on the values the
             // weight dtype will hold (so that a consumer's mean subtraction matches what its MFMA multiplied)
             float ps = 0.f, pq = 0.f;
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             ps += __shfl_xor(ps, 16); pq += __shfl_xor(pq, 16);
             ps += __shfl_xor(ps, 32); pq += __shfl_xor(pq, 32);
             if (ln < 16 && row < a.M) {
-                float* st2 = a.xstat + (((size_t)blockIdx.y * (a.N / 16) + nb0 + i) * 32 + 16 * hsel + ln) * 2;
+                float* st2 = a.xstat + (((size_t)blockIdx.y * (a.N / 16) + nb0 + i) * 32 + 16 * (H2 == 2 ? h : hsel) + ln) * 2;
                 st2[0] = ps;
                 st2[1] = pq;
             }
@@ -498,6 +507,7 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     dim3 grid((a.N + 16 * NB - 1) / (16 * NB), (a.M + 31) / 32);
     if (H2 == 1) grid.x = ((grid.x + 7) / 8) * 16;     // groups of 8 blocks x 2 halves
     if (H2 == 1 && !STAGE && !FOLD && a.W2) grid.x += ((a.N2 / 16 + 7) / 8) * 16;   // + the look-ahead role
+    if (H2 == 2 && !STAGE && !FOLD && a.W2) grid.x += a.N2 / (16 * NB);              // + the look-ahead role, 32-row workgroups
     auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
@@ -525,7 +535,7 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     const int nw = ksteps > 64 ? 16 : (ksteps > 16 ? 8 : 4);   // <= 8 (K<=2048 bf16) / 4 tiles in flight per wave
     // few feature blocks and more than 16 live rows: one 16-row half per workgroup doubles the busy CUs
     // (with a second role the half-split grid is used for every M: the arithmetic must not depend on the batch size)
-    const bool halves = a.N <= 2048 && (a.M > 16 || a.W2) && a.epi != EPI_GATED_FRAG;
+    const bool halves = a.N <= 2048 && (a.M > 16 || a.W2) && a.epi != EPI_GATED_FRAG && !(a.W2 && a.wide2);
     if (a.fold && a.force_halves && halves) {     // diagnostics only (ptts_test_gemm prologue 6)
         if (nw == 16) return launch_one<P, 16, 1, false, 1, 1, true>(a, stream);
         if (nw == 8) return launch_one<P, 8, 1, false, 1, 1, true>(a, stream);
