@@ -775,6 +775,29 @@ def test_two_m_tiles_batch_40_fp32(hip):
     assert torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe])
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_batch_sizes_1_17_33_reproduce_fixture_rows(hip, dtype):
+    """Utterances are independent (no cross-row op anywhere), so any batch built from the fixture's rows must reproduce
+    their codes: batch 1 (BASELINE configs[0]), 17 (one partly filled 32-row m-tile, the half-split GEMM grid with an
+    almost empty second half) and 33 (a second m-tile with one row).  fp32: bit-exact against the reference's codes;
+    bf16: every copy of a row gives the same codes as every other copy."""
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, dtype)
+    desc, amask, prompt, pmask = case_inputs(f)
+    enc = torch.from_numpy(f["enc_t5"])
+    want = torch.from_numpy(f["codes"])
+    for B in (1, 17, 33):
+        rows = [i % desc.shape[0] for i in range(B)]
+        got = model.generate(encoder_outputs=(enc[rows],), attention_mask=amask[rows], prompt_input_ids=prompt[rows],
+                             do_sample=False, max_length=int(f["max_length"]), return_raw_ids=True)[0].cpu()
+        assert got.shape[0] == B
+        if dtype == "fp32":
+            assert torch.equal(got, want[rows]), B
+        else:
+            for i in range(B):
+                assert torch.equal(got[i], got[rows[i]]), (B, i)
+
+
 def test_long_description_long_prompt_and_page_crossings_fp32(hip):
     """Lengths the fixtures never reach: a description of 90 tokens (cross-attention over two KV pages on the general
     kernel, T5 over 90 positions), a left-padded prompt of 70 tokens (prefill crosses a page), 60 generated columns (self

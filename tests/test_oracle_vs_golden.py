@@ -44,6 +44,31 @@ def test_delay_mask_docstring_example():
     assert frames_kept(8, 4) == 4 and frames_kept(6, 4) == 6
 
 
+def test_delay_pattern_round_trip_property():
+    """Size-independent property used at sizes no fixture covers: frames [B, K, F] written through the delay pattern
+    (codebook k shifted by k columns behind its BOS run) and read back by the un-delay of M:2633-2648 are the same frames,
+    for random shapes including the BASELINE length (K = 9, L = 2580)."""
+    g = torch.Generator().manual_seed(3)
+    for (B, K, L) in [(1, 4, 8), (2, 9, 17), (3, 9, 40), (2, 2, 3), (1, 9, 2580), (4, 5, 33)]:
+        bos, pad = 1025, 1024
+        start = torch.full((B * K, 1), bos, dtype=torch.long)
+        _, pat = build_delay_pattern_mask(start, bos, pad, L, K)
+        F = frames_kept(L, K)
+        frames = torch.randint(0, 1024, (B, K, F), generator=g)
+        raw = torch.randint(0, 1024, (B * K, L), generator=g)          # whatever the loop sampled where the pattern overrides
+        free = pat == -1
+        assert int(free.sum()) == B * K * F
+        raw[free] = frames.reshape(B * K, F).reshape(-1)
+        out = apply_delay_pattern_mask(raw, pat)
+        keep = (pat != bos) & (pat != pad)
+        back = out[keep].reshape(B, K, -1)
+        assert torch.equal(back, frames)
+        # row k is free exactly on columns k+1 .. k+F
+        for k in range(K):
+            cols = torch.nonzero(free[k]).flatten()
+            assert cols[0].item() == k + 1 and cols[-1].item() == k + F and len(cols) == F
+
+
 def test_delay_mask_prompt_too_long_raises():
     with pytest.raises(RuntimeError):
         build_delay_pattern_mask(torch.zeros(4, 7, dtype=torch.long), 7, 9, 8, 4)
