@@ -587,6 +587,14 @@ def test_generate_with_audio_prompt(hip):
     # the waveform path: prompt audio + continuation come back as one clip
     wav = model.generate(input_values=audio, max_new_tokens=12, **{k: v for k, v in kw.items() if k != "return_raw_ids"})
     assert wav.dim() == 2 and wav.shape[0] == B and torch.isfinite(wav).all()
+    # the codec does not depend on the decoder's storage type: a bf16 engine encodes the prompt to the same ids, and its
+    # prefix columns (teacher-forced by the delay pattern) are the fixture's codes
+    del model
+    torch.cuda.empty_cache()
+    m16 = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device="cuda:0")
+    assert torch.equal(m16.audio_encoder.encode(audio).audio_codes.cpu()[0], codes)
+    out16 = m16.generate(input_values=audio, max_new_tokens=12, **kw)
+    assert torch.equal(out16.cpu()[0][:, :, : n_pre - K + 1], codes[:, :, : n_pre - K + 1])
 
 
 # ------------------------------------------------------------------------------------------------
