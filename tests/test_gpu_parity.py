@@ -693,8 +693,12 @@ def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
     from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
     from parler_tts_amd.weights import save_pretrained
 
+    from parler_tts_amd.weights import synthetic_dac_encoder_state_dict
+
     f, meta = load_case("tiny_greedy")
     cfg, sd = state_dict_for("tiny_greedy", meta, parts=("text_encoder", "decoder", "audio_encoder"))
+    sd = dict(sd)
+    sd.update(synthetic_dac_encoder_state_dict(cfg.audio_encoder, seed=7))      # a full checkpoint carries the codec encoder too
     # write the codec convs the way a descript checkpoint stores them: weight_g / weight_v pairs
     disk = {}
     for k, v in sd.items():
@@ -713,6 +717,15 @@ def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
     wav = model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt)   # config defaults: greedy, L=24
     assert np.array_equal(model.last_codes[0].cpu().numpy(), f["codes"])
     assert wav.shape == (3, f["codes"].shape[-1] * cfg.audio_encoder.hop_length)
+    # the encode side came through the same loader (weight-norm folded): audio prompts work on a loaded checkpoint and agree
+    # with the CPU restatement on the un-normed tensors (random audio, no margin scan: a near-tie may flip)
+    from oracle import cpu_ref
+
+    g = torch.Generator().manual_seed(9)
+    audio = (torch.rand(2, 1, cfg.audio_encoder.hop_length * 30 + 7, generator=g) * 2 - 1) * 0.5
+    got = model.audio_encoder.encode(audio).audio_codes.cpu()
+    ref = cpu_ref.dac_encode(cfg, sd, audio)
+    assert got.shape == ref.shape and (got == ref).float().mean().item() > 0.99
     _models.clear()
 
 
