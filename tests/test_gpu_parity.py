@@ -661,6 +661,32 @@ def test_generate_with_guidance_scale(hip):
     assert np.array_equal(codes[0].cpu().numpy(), f["codes"])
 
 
+def test_max_length_below_two_codebook_spans(hip):
+    """max_length < 2K - 1: build_delay_pattern_mask returns an all-(-1) mask (M:105-106), so nothing is forced, the un-delay
+    keeps every column including the start column, and the special id there sends the codec through the per-sample path
+    that drops such frames (M:2654-2680).  fp32 engine vs the oracle: ids bit-exact, waveform close."""
+    from oracle import cpu_ref
+
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, "fp32")
+    _, sd = state_dict_for("tiny_greedy", meta, parts=("text_encoder", "decoder", "audio_encoder"))
+    desc, amask, prompt, pmask = case_inputs(f)
+    K = cfg.decoder.num_codebooks
+    L = 2 * K - 2
+    enc = torch.from_numpy(f["enc_t5"])
+    kw = dict(encoder_outputs=(enc,), attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L)
+    ids = model.generate(return_raw_ids=True, **kw)
+    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, pmask, L)
+    assert bool((ref["pattern"] == -1).all())
+    assert torch.equal(model.last_raw_ids.cpu(), ref["raw_ids"])
+    want = cpu_ref.undelay(cfg, ref["raw_ids"], ref["pattern"])
+    assert want.shape[-1] == L and torch.equal(ids.cpu(), want)          # every column kept, start column included
+    wav = model.generate(**kw).cpu()
+    ref_wav = cpu_ref.codes_to_waveform(cfg, sd, want)
+    assert wav.shape == ref_wav.shape == (desc.shape[0], (L - 1) * cfg.audio_encoder.hop_length)
+    assert float((wav - ref_wav).pow(2).mean().sqrt()) < 1e-4
+
+
 def test_streamer_protocol(hip):
     """put(start ids) once, then one put per generated column, then end() (M:2540-2541 + the HF loop)"""
     f, meta = load_case("tiny_greedy")
