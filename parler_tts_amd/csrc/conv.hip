@@ -351,7 +351,9 @@ __global__ void dac_latent_kernel(const long long* codes, const float* table, fl
         float s = 0.f;
         for (int k = 0; k < K; ++k) {
             const long long code = codes[((size_t)b * K + k) * F + f];
-            s = s + table[((size_t)k * ncodes + code) * C + c];
+            // precondition (checked by the host layer): 0 <= code < ncodes; an id outside contributes nothing instead of
+            // reading past the table
+            if ((unsigned long long)code < (unsigned long long)ncodes) s = s + table[((size_t)k * ncodes + code) * C + c];
         }
         z[((size_t)b * F + f) * C + c] = s;
     }

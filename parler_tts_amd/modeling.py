@@ -166,6 +166,10 @@ class HipEngine:
         B, K, F = codes.shape
         hop = self.cfg.audio_encoder.hop_length
         codes = codes.to(self.device, torch.int64).contiguous()
+        # ids the LM heads can emit but the codebooks do not hold (codebook_size .. vocab_size-1, SURVEY 8a note (v)): the
+        # reference fails in the codebook embedding lookup with an IndexError; the kernel must never see them
+        if codes.numel() and (int(codes.max()) >= self.cfg.audio_encoder.codebook_size or int(codes.min()) < 0):
+            raise IndexError("index out of range in self: codec ids must be in [0, codebook_size)")
         out = torch.empty(B, F * hop, device=self.device, dtype=torch.float32)
         _hip.check(self.lib.ptts_dac_decode(self.handle, B, F, _ptr(codes), _ptr(out), _stream()))
         torch.cuda.current_stream().synchronize()   # `codes` may be a temporary

@@ -437,6 +437,10 @@ def test_dac_decode_kernels(hip, name):
     assert np.abs(wav - f["wav"]).max() < 1e-4
     with pytest.raises(ValueError):
         dac.decode(torch.zeros(2, 1, codes.shape[1], 3, dtype=torch.long), [None])
+    bad = codes.clone()
+    bad[0, -1, 0] = cfg.audio_encoder.codebook_size + 2      # an id the LM heads can emit but no codebook holds
+    with pytest.raises(IndexError):
+        dac.decode(bad[None], [None])
 
 
 def test_dac_decode_long_clip_chunked_equals_unchunked(hip):
