@@ -539,6 +539,16 @@ class ParlerTTSForConditionalGeneration:
         if sample and gen.num_return_sequences > 1:
             raise NotImplementedError("num_return_sequences > 1: repeat the batch rows instead")
 
+        # id ranges: the reference fails with an IndexError in its embedding lookups; the gather kernels must never be handed
+        # an id outside their tables
+        def _in_range(name, t, hi):
+            if t is not None and t.numel() and (int(t.min()) < 0 or int(t.max()) >= hi):
+                raise IndexError(f"index out of range in self: `{name}` must be in [0, {hi})")
+
+        if enc_out is None:
+            _in_range("input_ids", input_ids, cfgm.text_encoder.vocab_size)
+        _in_range("prompt_input_ids", prompt_ids, cfgm.vocab_size)
+        _in_range("decoder_input_ids", ids, dec.vocab_size + 1)       # embed_tokens has vocab_size + 1 rows (M:769-773)
         eng = self.engine(B_eff, T, P, L)
         import time as _time
 

@@ -401,6 +401,22 @@ def test_generate_api_errors(hip):
         model.audio_encoder.decode(torch.zeros(2, 1, 4, 3, dtype=torch.long), [None])
 
 
+def test_generate_rejects_ids_outside_the_tables(hip):
+    """ids past an embedding table: IndexError as from the reference's nn.Embedding, never an out-of-bounds gather"""
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, "fp32")
+    desc, amask, prompt, _ = case_inputs(f)
+    kw = dict(attention_mask=amask, do_sample=False, max_length=12)
+    with pytest.raises(IndexError):
+        model.generate(input_ids=desc + cfg.text_encoder.vocab_size, prompt_input_ids=prompt, **kw)
+    with pytest.raises(IndexError):
+        model.generate(input_ids=desc, prompt_input_ids=prompt + cfg.vocab_size, **kw)
+    K = cfg.decoder.num_codebooks
+    with pytest.raises(IndexError):
+        model.generate(input_ids=desc, prompt_input_ids=prompt,
+                       decoder_input_ids=torch.full((desc.shape[0] * K, 2), cfg.decoder.vocab_size + 1), **kw)
+
+
 def test_generate_eos_paths(hip):
     """EOS rows: the per-sample (sequential) codec path and the reference's frame filter."""
     from oracle import cpu_ref
