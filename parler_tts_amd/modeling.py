@@ -545,6 +545,14 @@ class ParlerTTSForConditionalGeneration:
             if t is not None and t.numel() and (int(t.min()) < 0 or int(t.max()) >= hi):
                 raise IndexError(f"index out of range in self: `{name}` must be in [0, {hi})")
 
+        if tuple(attention_mask.shape) != (B, T):
+            raise ValueError(f"attention_mask must be [batch {B}, description length {T}], got {tuple(attention_mask.shape)}")
+        if prompt_ids is not None and (prompt_ids.dim() != 2 or prompt_ids.shape[0] != B):
+            raise ValueError(f"prompt_input_ids must be [batch {B}, prompt_len], got {tuple(prompt_ids.shape)}")
+        if prompt_mask is not None and tuple(prompt_mask.shape) != (B, P):
+            raise ValueError(f"prompt_attention_mask must be [batch {B}, prompt length {P}], got {tuple(prompt_mask.shape)}")
+        if enc_out is not None and enc.shape[-1] != cfgm.text_encoder.d_model:
+            raise ValueError(f"encoder_outputs must be [batch, T, {cfgm.text_encoder.d_model}], got {tuple(enc.shape)}")
         if enc_out is None:
             _in_range("input_ids", input_ids, cfgm.text_encoder.vocab_size)
         _in_range("prompt_input_ids", prompt_ids, cfgm.vocab_size)

@@ -415,6 +415,13 @@ def test_generate_rejects_ids_outside_the_tables(hip):
     with pytest.raises(IndexError):
         model.generate(input_ids=desc, prompt_input_ids=prompt,
                        decoder_input_ids=torch.full((desc.shape[0] * K, 2), cfg.decoder.vocab_size + 1), **kw)
+    # shapes the raw pointers behind the C ABI cannot check
+    with pytest.raises(ValueError):
+        model.generate(input_ids=desc, prompt_input_ids=prompt, attention_mask=amask[:, :-1], do_sample=False, max_length=12)
+    with pytest.raises(ValueError):
+        model.generate(input_ids=desc, prompt_input_ids=prompt, prompt_attention_mask=torch.ones(desc.shape[0], 1), **kw)
+    with pytest.raises(ValueError):
+        model.generate(input_ids=desc, prompt_input_ids=prompt[:-1], **kw)
 
 
 def test_generate_eos_paths(hip):
