@@ -15,6 +15,8 @@
  *     NULL (the legacy default stream, which cannot be captured into a hipGraph) is accepted too: the
  *     work then runs on a stream the engine owns and the call is host-synchronous (it waits for the
  *     NULL stream before starting and returns when its own work has finished)
+ *   - token ids index embedding tables directly: the caller guarantees 0 <= id < rows (the Python layer raises IndexError
+ *     first, as the reference's nn.Embedding does); tensor extents follow from the size arguments and cannot be checked here
  *   - return value: 0 = ok, negative = PTTS_E_* ; ptts_last_error() gives the text (HIP error
  *     strings included); no exceptions cross the ABI
  *   - one engine per device; not thread-safe per engine, re-entrant across engines
