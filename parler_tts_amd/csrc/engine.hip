@@ -1491,8 +1491,8 @@ int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* 
         HIP_TRY(rows_to_frag_launch(X, xf, M, K, dtype, s));
         g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = xf;
     }
-    const bool force_halves = prologue == 6;   // 6 = 4 on the half-split workgroup (diagnostics)
-    if (force_halves) prologue = 4;
+    const bool force_whole = prologue == 6;   // 6 = 4 kept on the two-half workgroup where the half-split grid would be chosen (A/B)
+    if (force_whole) prologue = 4;
     if (prologue == 4) {   // LayerNorm through the folded path: gamma into the weights, raw rows as fragments
         const size_t mrows = (size_t)(M + 31) / 32 * 32;
         HIP_TRY(hipMalloc(&wf, (size_t)Np * K * esz));
@@ -1503,7 +1503,7 @@ int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* 
         HIP_TRY(fold_layernorm_launch(wp, wf, gamma, beta, c1, c2, Np, K, dtype, s));
         HIP_TRY(rows_to_frag_launch(X, xf, M, K, dtype, s));
         g.W = wf; g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = xf; g.fold = 1; g.c1 = c1; g.c2 = c2;
-        g.force_halves = force_halves ? 1 : 0;
+        g.force_whole = force_whole ? 1 : 0;
     }
     int v = gemm_validate(g, dtype);
     hipError_t he = hipSuccess;

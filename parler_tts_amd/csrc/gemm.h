@@ -22,7 +22,7 @@ struct GemmArgs {
     // folded LayerNorm (PRO_FRAG only): `xfrag` holds the RAW residual rows, W is diag(gamma).W, and the
     // normalisation is applied after the MFMA: y = rstd * (x.W' - mean * c1) + c2   (see fold_layernorm_launch)
     int fold = 0;
-    int force_halves = 0;         // test hook only: run the folded GEMM on the half-split workgroup
+    int force_whole = 0;          // test hook only: keep the folded GEMM on the two-half workgroup where the half-split grid would be chosen
     int wide2 = 0;                // with W2: 32-row workgroups for BOTH roles (N/16 + N2/16 workgroups per m-tile) instead of the
                                   // half-split grid: fewer, fatter workgroups so that the launch is one round of one workgroup per CU
     const float* c1 = nullptr;    // [N] sum_k W'[n][k]

@@ -21,7 +21,8 @@
 //   * the residual out-projection of the self-attention can carry a second ROLE in the same launch: extra
 //     workgroups compute the look-ahead cross-attention query  [x | a] . [Wq' ; Wq'.Wo]^T  
 //   * code-generation rules learnt the hard way: tile guards must be scalar (MFMA ignores
-//     EXEC), >64-bit LDS stores are issued with their drain, operands of queued MFMAs keep their own registers
+//     EXEC), MFMA results never feed an inline-asm instruction (no hazard padding there), operands of queued
+//     MFMAs keep their own registers
 //
 // Reference arithmetic: nn.Linear (bias-free) M:256-259, LayerNorm M:402-413/446/467/487/959,
 // q scaling M:282, KV append M:299-304, GELU MLP M:488-490, LM heads M:1143, enc_to_dec_proj M:2010-2017,
@@ -381,8 +382,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                                 pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(y1, bf16x2));
                                 *reinterpret_cast<uint2*>(dst) = pk;
                             } else {
-                                // 128-bit LDS store: issued with its drain (ptts_common.h: lds_store_b128_drain)
-                                lds_store_b128_drain(dst, f32x4{y0[0], y0[1], y1[0], y1[1]});
+                                lds_store_b128(dst, f32x4{y0[0], y0[1], y1[0], y1[1]});
                             }
                         }
                     }
@@ -422,11 +422,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // ---- K-split reduction in fixed wave order, then the fused epilogue ----
     f32x4* redv = reinterpret_cast<f32x4*>(red);
     if (STAGE) __syncthreads();   // all B-fragment reads of the stage image have retired
-    // hand-over through LDS: store + drain as one unit (lds_store_*_drain in ptts_common.h explains why)
+    // hand-over through LDS: plain stores, so hipcc pads the MFMA -> ds_write hazard (ptts_common.h)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        lds_store_b128_drain(&redv[((w * NB + i) * 2 + 0) * 64 + lane], acc[i][0]);
-        if (H2 == 2) lds_store_b128_drain(&redv[((w * NB + i) * 2 + 1) * 64 + lane], acc[i][1]);
+        lds_store_b128(&redv[((w * NB + i) * 2 + 0) * 64 + lane], acc[i][0]);
+        if (H2 == 2) lds_store_b128(&redv[((w * NB + i) * 2 + 1) * 64 + lane], acc[i][1]);
     }
     // per wave and 16-row half: sum(x) and sum(x^2) of its k-steps for the 16 rows (lanes l, l+16, l+32, l+48 hold
     // the four k-groups of row l & 15)
@@ -438,8 +438,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
             sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
             if (lane < 16) {
-                lds_store_b32_drain(&stat[((w * 2 + h) * 2 + 0) * 16 + lane], sv);
-                lds_store_b32_drain(&stat[((w * 2 + h) * 2 + 1) * 16 + lane], qv);
+                lds_store_b32(&stat[((w * 2 + h) * 2 + 0) * 16 + lane], sv);
+                lds_store_b32(&stat[((w * 2 + h) * 2 + 1) * 16 + lane], qv);
             }
         }
     }
@@ -536,15 +536,15 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     // few feature blocks and more than 16 live rows: one 16-row half per workgroup doubles the busy CUs
     // (with a second role the half-split grid is used for every M: the arithmetic must not depend on the batch size)
     const bool halves = a.N <= 2048 && (a.M > 16 || a.W2) && a.epi != EPI_GATED_FRAG && !(a.W2 && a.wide2);
-    if (a.fold && a.force_halves && halves) {     // diagnostics only (ptts_test_gemm prologue 6)
-        if (nw == 16) return launch_one<P, 16, 1, false, 1, 1, true>(a, stream);
-        if (nw == 8) return launch_one<P, 8, 1, false, 1, 1, true>(a, stream);
-        return launch_one<P, 4, 1, false, 1, 1, true>(a, stream);
-    }
     if (a.fold) {
-        // always the two-half workgroup: the half-split folded instance (cross-q) was the one configuration that
-        // stayed non-repeatable when two processes shared the GPU (about 1 launch in 3e4),
-        // while this one ran 4e5 shared launches clean.  Costs cross-q ~0.3 us per launch.
+        // Round 1 kept the half-split folded instance out of the product path because it was the one configuration
+        // that stayed non-repeatable with two processes on the GPU; its K-split hand-over was an inline-asm ds_write
+        // behind the last MFMA with no hazard padding (ptts_common.h).  With plain stores it is instantiated again.
+        if (halves && !a.force_whole) {
+            if (nw == 16) return launch_one<P, 16, 1, false, 1, 1, true>(a, stream);
+            if (nw == 8) return launch_one<P, 8, 1, false, 1, 1, true>(a, stream);
+            return launch_one<P, 4, 1, false, 1, 1, true>(a, stream);
+        }
         if (nw == 16) return launch_one<P, 16, 1, false, 1, 2, true>(a, stream);
         if (nw == 8) return launch_one<P, 8, 1, false, 1, 2, true>(a, stream);
         return launch_one<P, 4, 1, false, 1, 2, true>(a, stream);

@@ -110,21 +110,18 @@ struct StepState {
     int pad_;
 };
 
-// ---- LDS stores whose operand registers must not be recycled early --------------------------------------------
-// hipcc may overwrite the address or data VGPR of a ds_write in the very next VALU instruction (it assumes the
-// store has read its operands when it issues; for >64-bit data it leaves two wait states).  With the LDS queue
-// backed up - e.g. another process's workgroups on the same CU - a 128-bit store was observed to pick up the NEW
-// register contents (wrong K-split partials about once in 2e3..3e4 launches, only under GPU sharing).  These
-// helpers issue the store and drain the LDS queue inside one asm statement, so both operands stay live.
-__device__ inline uint32_t lds_addr(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ inline void lds_store_b128_drain(void* p, f32x4 v) {
-    asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds_addr(p)), "v"(v) : "memory");
-}
-__device__ inline void lds_store_b32_drain(void* p, float v) {
-    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds_addr(p)), "v"(v) : "memory");
-}
+// ---- K-split hand-over stores --------------------------------------------------------------------------------
+// MFMA accumulators go to LDS through PLAIN C++ stores, never through an `asm` statement: hipcc pads the gfx950
+// "XDL write VGPR -> LDS/VMEM/VALU read" hazard (8 wait states behind v_mfma_f32_16x16x32_bf16, 10 behind
+// v_mfma_f32_16x16x4_f32 - what it emits for a bare MFMA -> ds_write pair) only for instructions it models, and an
+// inline-asm ds_write is opaque to its hazard recognizer (cdna_hip_programming.md section 5.7 item 2).  Round 1
+// issued these stores as `asm("ds_write_b128 ...; s_waitcnt lgkmcnt(0)")` straight behind the last MFMA of the
+// K loop; tools/check_mfma_asm_hazard.py found 35 (MFMA, asm store) pairs in 9 instances closer than the table
+// allows (8-10 wait states on the shortest path), i.e. a store that can read an accumulator register the matrix
+// pipe has not finished retiring: one register, its last-written lanes - the signature DESIGN.md section 7 records.
+// The lint runs in the CPU test suite and fails on any inline-asm reader of an MFMA result.
+__device__ inline void lds_store_b128(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ inline void lds_store_b32(void* p, float v) { *reinterpret_cast<float*>(p) = v; }
 
 // ---- wave64 all-reduce helpers on DPP (VALU data-parallel primitives: no LDS crossbar round trips) ----
 // gfx9 DPP controls: quad_perm 0x00-0xFF, row_ror:n 0x120+n, row_mirror 0x140, row_half_mirror 0x141.

@@ -132,3 +132,40 @@ def test_no_mfma_is_guarded_by_exec_masking_only():
     spec.loader.exec_module(mod)
     srcs = [os.path.join(root, "parler_tts_amd", "csrc", f) for f in ("gemm.hip", "conv.hip")]
     assert mod.main(srcs) == 0
+
+
+def test_no_mfma_result_is_read_by_inline_asm_too_early():
+    """hipcc pads the gfx950 "MFMA writes a VGPR -> LDS / VMEM / VALU reads it" hazard only for instructions it models;
+    an `asm` statement is opaque to it.  tools/check_mfma_asm_hazard.py walks every control-flow path backwards from
+    every inline-asm instruction and fails on an MFMA result read closer than LLVM's own wait-state table allows
+    (round 1's K-split hand-over was such a pair; ptts_common.h).  The scanner's self-test proves it still sees one."""
+    import importlib.util
+    import os
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_mfma_asm_hazard", os.path.join(root, "tools", "check_mfma_asm_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    srcs = [os.path.join(root, "parler_tts_amd", "csrc", f) for f in ("gemm.hip", "conv.hip", "attn.hip")]
+    assert mod.main(srcs) == 0
+    # positive control: the round-1 pattern in ten lines must be flagged
+    probe = r'''
+#include <hip/hip_runtime.h>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__global__ void k(const bf16x8* a, const bf16x8* b, float* o) {
+    __shared__ f32x4 sh[64];
+    f32x4 c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[threadIdx.x], b[threadIdx.x], c, 0, 0, 0);
+    unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&sh[threadIdx.x];
+    asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(c) : "memory");
+    __syncthreads();
+    o[threadIdx.x] = sh[threadIdx.x ^ 1][0];
+}
+'''
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "probe.hip")
+        open(src, "w").write(probe)
+        assert mod.main([src]) == 1
