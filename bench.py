@@ -53,29 +53,43 @@ def synth_inputs(cfg, B, T, P, seed):
     return desc, prompt
 
 
-def cpu_baseline(cfg, sd, B, T, P, L, budget_s=25.0):
-    """Bounded sample of the CPU port on the same workload: decode steps at the start of the run
-    (S ~ P) and in the middle (S ~ L/2) with the reference's cat-grown KV cache, integrated over the
-    whole run with the linear-in-S cost model of BASELINE.md section 4."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, sd, B, T, P, L, budget_s=25.0, full_b1=False):
+    """Bounded sample of the CPU port on the same workload (BASELINE.md section 4): decode steps at the start of the run
+    (S ~ P) and in the middle (S ~ P + L/2), integrated over the whole run with the linear-in-S cost model.  Three legs:
+    the reference-shaped cat-grown KV cache at batch B (`value`: what the reference's own code does, M:303-304), a static
+    preallocated KV cache at batch B (no re-copy: the fair algorithmic baseline) and batch 1 (the reference's README use)."""
     from oracle import cpu_ref
 
     torch.manual_seed(0)
     dec = cfg.decoder
     K, D, H = dec.num_codebooks, dec.hidden_size, dec.num_attention_heads
-    enc_h = torch.randn(B, T, D) * 0.1
-    amask = torch.ones(B, T, dtype=torch.long)
 
-    def timed_steps(S0, n):
-        # KV cache of S0 positions filled with noise (values do not change the cost), reference-shaped
-        # cat-grown self K/V (M:303-304) and pre-projected cross K/V (M:287-294)
-        cache = cpu_ref.KVCache("cat")
+    def timed_steps(Bx, S0, n, mode):
+        # KV cache of S0 positions filled with noise (values do not change the cost) and pre-projected cross K/V (M:287-294)
+        enc_h = torch.randn(Bx, T, D) * 0.1
+        amask = torch.ones(Bx, T, dtype=torch.long)
+        cache = cpu_ref.KVCache(mode, max_len=S0 + n + 2)
         for _ in range(dec.num_hidden_layers):
-            cache.self_k.append(torch.randn(B, H, S0, D // H) * 0.1)
-            cache.self_v.append(torch.randn(B, H, S0, D // H) * 0.1)
-            cache.cross_k.append(torch.randn(B, H, T, D // H) * 0.1)
-            cache.cross_v.append(torch.randn(B, H, T, D // H) * 0.1)
+            if mode == "cat":
+                cache.self_k.append(torch.randn(Bx, H, S0, D // H) * 0.1)
+                cache.self_v.append(torch.randn(Bx, H, S0, D // H) * 0.1)
+            else:
+                cache.self_k.append(torch.randn(Bx, H, S0 + n + 2, D // H) * 0.1)
+                cache.self_v.append(torch.randn(Bx, H, S0 + n + 2, D // H) * 0.1)
+            cache.cross_k.append(torch.randn(Bx, H, T, D // H) * 0.1)
+            cache.cross_v.append(torch.randn(Bx, H, T, D // H) * 0.1)
         cache.length = S0
-        ids = torch.randint(0, 1024, (B * K, 1))
+        ids = torch.randint(0, 1024, (Bx * K, 1))
         cpu_ref.decoder_forward(cfg, sd, ids, enc_h, amask, None, None, cache)   # warm-up
         ts = []
         for _ in range(n):
@@ -88,24 +102,40 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=25.0):
     best = None
     for nt in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
-        t, _ = timed_steps(P + 1, 2)
+        t, _ = timed_steps(B, P + 1, 2, "cat")
         if best is None or t < best[0]:
             best = (t, nt)
     cores = best[1]
     torch.set_num_threads(cores)
-    t_lo, s_lo = timed_steps(P + 1, 6)
-    s_mid = P + L // 2
-    n_hi = max(2, min(6, int((budget_s - 6 * t_lo) / max(t_lo * 6, 1e-3))))
-    t_hi, s_hi = timed_steps(s_mid, n_hi)
-    slope = (t_hi - t_lo) / max(s_hi - s_lo, 1)
     steps = L - 1
-    total = sum(t_lo + slope * ((P + 1 + i) - s_lo) for i in range(steps))
-    return {
-        "value": round(B * K * steps / total, 2), "unit": "codec tokens/s", "cores": cores, "kind": "port",
-        "sample": (f"decode loop only (no T5/DAC), B={B}: 6 steps at S={s_lo - 6}..{s_lo} ({t_lo * 1e3:.0f} ms/step) and "
-                   f"{n_hi} steps at S~{s_hi} ({t_hi * 1e3:.0f} ms/step), reference-shaped cat-grown KV, fp32, "
-                   f"{cores} torch threads; integrated over {steps} steps with a linear-in-S model"),
+
+    def leg(Bx, mode, budget):
+        t_lo, s_lo = timed_steps(Bx, P + 1, 6, mode)
+        n_hi = max(2, min(6, int((budget - 6 * t_lo) / max(t_lo * 6, 1e-3))))
+        t_hi, s_hi = timed_steps(Bx, P + L // 2, n_hi, mode)
+        slope = (t_hi - t_lo) / max(s_hi - s_lo, 1)
+        total = sum(t_lo + slope * ((P + 1 + i) - s_lo) for i in range(steps))
+        return Bx * K * steps / total, (f"6 steps at S~{s_lo} ({t_lo * 1e3:.0f} ms/step) and {n_hi} at S~{s_hi} "
+                                        f"({t_hi * 1e3:.0f} ms/step)")
+
+    v_cat, d_cat = leg(B, "cat", budget_s * 0.55)
+    v_static, d_static = leg(B, "static", budget_s * 0.35)
+    v_b1, d_b1 = leg(1, "cat", budget_s * 0.1)
+    out = {
+        "value": round(v_cat, 2), "unit": "codec tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+        "static_kv_value": round(v_static, 2), "batch1_value": round(v_b1, 2),
+        "sample": (f"decode loop only (no T5/DAC), fp32, {cores} torch threads, each leg integrated over {steps} steps with a "
+                   f"linear-in-S model: value = B={B} reference-shaped cat-grown KV [{d_cat}]; static_kv_value = B={B} "
+                   f"preallocated KV [{d_static}]; batch1_value = B=1 cat-grown [{d_b1}]"),
     }
+    if full_b1:      # one FULL batch-1 run of the port (minutes), not part of the default bench
+        enc = torch.randn(1, T, cfg.text_encoder.d_model)
+        prompt = torch.randint(2, 32100, (1, P))
+        t0 = time.perf_counter()
+        r = cpu_ref.generate_ids(cfg, sd, enc, torch.ones(1, T, dtype=torch.long), prompt, None, L)
+        dt = time.perf_counter() - t0
+        out["batch1_full_run"] = {"seconds": round(dt, 1), "codec_tokens_per_s": round(K * (r["raw_ids"].shape[1] - 1) / dt, 2)}
+    return out
 
 
 def main():
@@ -120,6 +150,7 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=16)
     ap.add_argument("--profile-every", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full-b1", action="store_true", help="also time one FULL batch-1 run of the CPU port (minutes)")
     ap.add_argument("--no-dac", action="store_true", help="stop at codec ids (diagnostic; not the headline)")
     args = ap.parse_args()
 
@@ -156,13 +187,33 @@ def main():
     sd = synthetic_state_dict(cfg, seed=1234, never_eos=True)
     model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=args.dtype, device=dev)
     model.profile_every = args.profile_every
-    desc, prompt = synth_inputs(cfg, B, T, P, seed=1234 + rank)   # every rank its own utterances (weak scaling)
+    # weak scaling: the job's batch is B utterances per GPU.  For N > 1 the whole batch lives on rank 0 and travels through
+    # parler_tts_amd.distributed.generate_data_parallel - broadcast of the id tensors, contiguous slices, local generate(),
+    # gather of the codec ids with per-row lengths - i.e. the API a multi-GPU user calls, inside the timed region.
+    desc, prompt = synth_inputs(cfg, B * world, T, P, seed=1234)
     desc, prompt = desc.to(dev), prompt.to(dev)
-    amask = torch.ones(B, T, dtype=torch.long, device=dev)
+    amask = torch.ones(B * world, T, dtype=torch.long, device=dev)
     model.audio_encoder  # build the codec before timing
-    kw = dict(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L)
+    kw = dict(do_sample=False, max_length=L)
     if args.no_dac:
         kw["return_raw_ids"] = True
+    coll_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
+
+    def one_pass():
+        if dist is None:
+            return model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, **kw)
+        from parler_tts_amd.distributed import generate_data_parallel
+
+        def local(**inp):      # full local generate() (waveforms stay on the rank), codec ids go to the gather
+            model.generate(**{k: v.to(dev) for k, v in inp.items()}, **kw)
+            return model.last_codes[0].to(coll_dev)
+
+        src = dict(input_ids=desc.to(coll_dev), attention_mask=amask.to(coll_dev), prompt_input_ids=prompt.to(coll_dev)) \
+            if rank == 0 else dict(input_ids=None, attention_mask=None, prompt_input_ids=None)
+        codes, frames = generate_data_parallel(local, **src, src=0, device=coll_dev, gather="codes",
+                                               pad_token_id=cfg.decoder.pad_token_id)
+        assert codes.shape[0] == B * world and int(frames.min()) == L - K
+        return codes
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -172,7 +223,7 @@ def main():
 
     out = None
     for _ in range(args.warmup):
-        out = model.generate(**kw)
+        out = one_pass()
     sync_all()
     model.engine().profile_read(reset=True)
     phase = {"t5_prefill_ms": 0.0, "decode_ms": 0.0, "post_ms": 0.0}
@@ -180,14 +231,8 @@ def main():
     t0 = time.perf_counter()
     pass_codes = []            # references only (no sync, no copy): compared after the timed region
     for _ in range(args.steps):
-        out = model.generate(**kw)
+        out = one_pass()
         pass_codes.append(model.last_codes)
-        if dist is not None:   # data-parallel plumbing: gather the codec ids of every rank (RCCL over xGMI)
-            codes = model.last_codes[0].to(torch.int32)
-            if dist.get_backend() != "nccl":
-                codes = codes.cpu()
-            gathered = [torch.empty_like(codes) for _ in range(world)]
-            dist.all_gather(gathered, codes)
     sync_all()
     dt = time.perf_counter() - t0
     # every timed pass ran the same inputs greedily: their codec ids must be identical (bit-repeatability check)
@@ -204,13 +249,18 @@ def main():
     prof = model.engine().profile_read(reset=True)
     if rank == 0:
         achieved = (prof.algo_bytes / 1e9) / (prof.total_ms / 1e3) if prof.total_ms > 0 else 0.0
-        traffic = None
+        # HBM traffic of the dominant kernel: NOT a counter reading of this run.  rocprofv3 --pmc passes (separate runs,
+        # profiles/README.md) give the ratio HBM fetch bytes / algorithmic bytes of the same kernel; it is applied to this
+        # run's own per-launch byte count and flagged as derived, with the source run named.
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_attn_traffic.json")
         if os.path.exists(pmc):
-            try:   # PMC ratio (HBM fetch / algorithmic bytes) of the same kernel, collected in separate --pmc passes
-                ratio = json.load(open(pmc)).get(args.dtype, {}).get("fetchx2_over_algo")
+            try:
+                rec = json.load(open(pmc)).get(args.dtype, {})
+                ratio = rec.get("fetchx2_over_algo")
                 if ratio and prof.launches:
                     traffic = round(ratio * prof.algo_bytes / prof.launches)
+                    traffic_src = rec.get("source", "profiles/pmc_attn_traffic.json")
             except Exception:
                 traffic = None
         line = {
@@ -220,11 +270,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"parler_tts_mini_v0.1 {args.dtype}, batch {B}/GPU greedy, T={T} P={P} max_length={L} "
                                    f"({n_steps} decode steps), full generate() incl. T5 encoder, prefill and DAC decode"
-                                   + (" [DAC skipped]" if args.no_dac else ""),
+                                   + (" [DAC skipped]" if args.no_dac else "")
+                                   + ("" if world == 1 else "; whole batch on rank 0 -> generate_data_parallel (broadcast ids, "
+                                      "slice, local generate, gather codec ids)"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "rtf_audio_s_per_wall_s": round(audio_s / dt, 2),
             "decode_loop_tokens_per_s": round(tokens / world / max(phase["decode_ms"] / 1e3, 1e-9), 1) if phase["decode_ms"] else None,
             "phase_ms_per_step_rank0": {k: round(v / args.steps, 2) for k, v in phase.items()},
+            # time to the first codec token: T5 encoder + prefill (enc_to_dec_proj, cross K/V, prompt positions) + one decode step
+            "ttft_ms_rank0": round(phase["t5_prefill_ms"] / args.steps + (phase["decode_ms"] / args.steps) / max(n_steps, 1), 2),
             "passes_bit_identical_rank0": repeatable,
             "decode_loop_roofline_rank0": decode_loop_roofline(cfg.decoder, B, T, P, n_steps, 2 if args.dtype == "bf16" else 4,
                                                                phase["decode_ms"] / args.steps / 1e3) if phase["decode_ms"] else None,
@@ -237,7 +291,8 @@ def main():
             "roofline": {
                 "kernel": "attn_decode_kernel (self-attention over the paged KV cache)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_derived": traffic is not None,
+                "traffic_source": traffic_src,
                 "launches_sampled": int(prof.launches),
                 "avg_launch_us": round(prof.total_ms * 1e3 / max(prof.launches, 1), 2),
                 "avg_algo_bytes_per_launch": round(prof.algo_bytes / max(prof.launches, 1)),
@@ -245,8 +300,8 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            sd_dec = {k: v for k, v in sd.items() if k.startswith("decoder.")}
-            line["cpu_baseline"] = cpu_baseline(cfg, sd_dec, B, T, P, L)
+            sd_dec = {k: v for k, v in sd.items() if not k.startswith(("text_encoder.", "audio_encoder."))}
+            line["cpu_baseline"] = cpu_baseline(cfg, sd_dec, B, T, P, L, full_b1=args.cpu_full_b1)
             line["speedup_vs_cpu_decode_loop"] = round(line["decode_loop_tokens_per_s"] / line["cpu_baseline"]["value"], 1) \
                 if line["decode_loop_tokens_per_s"] else None
         print(json.dumps(line), flush=True)

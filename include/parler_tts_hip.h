@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 5
+#define PTTS_ABI_VERSION 6
 
 enum { PTTS_DTYPE_F32 = 0, PTTS_DTYPE_BF16 = 1 };
 
@@ -149,6 +149,14 @@ typedef struct ptts_sampling {
     float guidance_scale;    /* > 1: rows [0,B*K) conditional, [B*K,2B*K) unconditional (M:2556-2558) */
     uint64_t seed;           /* Philox key; draws are (seed, row, step) so runs are reproducible */
     float top_p;             /* nucleus warper applied after top-k; <= 0 or >= 1 = off */
+    /* generation_config.eos_token_id / pad_token_id of THIS call (the third-party loop pads finished rows with the
+     * generation config's pad id and latches on its eos id, not on the decoder config's); -1 = the ptts_config values,
+     * eos_token_id <= -2 = no EOS criterion at all (generation_config.eos_token_id = None: rows never finish early) */
+    int32_t eos_token_id, pad_token_id;
+    /* MinLengthLogitsProcessor / MinNewTokensLengthLogitsProcessor of the third-party `_get_logits_processor` the
+     * reference calls at modeling_parler_tts.py:2561-2567: score[eos] = -inf while the id matrix has fewer than
+     * eos_free_until columns ( = max(min_length, start_len + min_new_tokens) ); 0 = off */
+    int32_t eos_free_until;
 } ptts_sampling;
 
 /* ---- decode: n_steps iterations of {prepare_inputs_for_generation (M:2081-2148), forward
@@ -189,6 +197,12 @@ int ptts_pool_info(ptts_engine* e, int32_t* n_pages, int32_t* max_blocks, int64_
  * token of that row before the pad-out / EOS latch, -1 leaves the row alone; NULL clears.  While set,
  * steps are launched eagerly. */
 int ptts_set_forced_tokens(ptts_engine* e, const int64_t* tokens_host, int32_t rows);
+
+/* Teacher forcing along a whole id matrix kept in DEVICE memory (parity tests at depth: thousands of steps under graph
+ * replay): the step that fills column c of raw_ids takes forced_ids[row][c] when that is >= 0, and writes the token it
+ * would have chosen itself to own_choice[row][c] (own_choice may be NULL).  Both [B*K][L] int64, caller-owned, alive until
+ * cleared; NULL forced_ids clears both.  Takes effect with the next ptts_prefill / ptts_decode_steps. */
+int ptts_set_forced_sequence(ptts_engine* e, const int64_t* forced_ids, int64_t* own_choice);
 
 /* Debug hooks for kernel-level parity tests: stop issuing kernels after n launches of each following
  * prefill / decode call (-1 = off; while on, steps run eagerly), and expose engine-owned buffers

@@ -321,6 +321,8 @@ def generate_ids(
     decoder_attention_mask: Optional[torch.Tensor] = None,
     prompt_hidden_states: Optional[torch.Tensor] = None,
     decoder_only: bool = False,
+    num_return_sequences: int = 1,
+    record_steps=None,
 ) -> Dict[str, torch.Tensor]:
     """The hot loop: M:2530-2537 (delay mask) + prepare_inputs_for_generation M:2081-2148 +
     forward M:1927-2079 + the third-party greedy/sample step.
@@ -364,8 +366,23 @@ def generate_ids(
             decoder_attention_mask = torch.cat([torch.ones_like(decoder_attention_mask)[:, :1], decoder_attention_mask], -1)
     dmask = decoder_attention_mask
     ids, pattern = build_delay_pattern_mask(ids, bos, pad, max_length, K)       # M:2530-2535
+    if num_return_sequences > 1:
+        # M:2600-2606 -> third-party `_expand_inputs_for_generation`: repeat_interleave(n, dim=0) of the id rows [B*K, s] and
+        # of every tensor kwarg - encoder states, masks, prompt states and the stashed delay pattern [B*K, L].  The decoder
+        # then reads row (b*K + k)*n + j as codebook ((b*K + k)*n + j) % K of utterance ((b*K + k)*n + j) // K (M:823).
+        n = num_return_sequences
+        rep = lambda t: None if t is None else t.repeat_interleave(n, dim=0)
+        if use_cfg:     # both guidance halves were concatenated before the expansion (M:2231-2237 precede M:2600)
+            h = enc_h.shape[0] // 2
+            enc_h = torch.cat([rep(enc_h[:h]), rep(enc_h[h:])])
+            amask = None if amask is None else torch.cat([rep(amask[:h]), rep(amask[h:])])
+            prompt_h = None if prompt_h is None else torch.cat([rep(prompt_h[:h]), rep(prompt_h[h:])])
+            pmask = None if pmask is None else torch.cat([rep(pmask[:h]), rep(pmask[h:])])
+        else:
+            enc_h, amask, prompt_h, pmask = rep(enc_h), rep(amask), rep(prompt_h), rep(pmask)
+        ids, pattern, dmask = rep(ids), rep(pattern), rep(dmask)
     cache = KVCache(kv_mode, max_len=(0 if prompt_h is None else prompt_h.shape[1]) + max_length)
-    unfinished = torch.ones(B * K, dtype=torch.long)
+    unfinished = torch.ones(ids.shape[0], dtype=torch.long)
     step_logits, margins = [], []
     step = 0
     while True:
@@ -383,7 +400,7 @@ def generate_ids(
             logits = cfg_combine(logits, guidance_scale)
         for proc in (logits_processor or []):      # user processors follow the guidance processor (M:2556-2567), before the warpers
             logits = proc(ids, logits)
-        if step < record_logits:
+        if step < record_logits or (record_steps is not None and step in record_steps):
             step_logits.append(logits.clone())
         if do_sample:
             probs = F.softmax(warp_logits(logits, temperature, top_k, top_p), dim=-1)
@@ -410,16 +427,17 @@ def generate_ids(
     return out
 
 
-def undelay(cfg: ParlerTTSConfig, raw_ids: torch.Tensor, pattern: torch.Tensor) -> torch.Tensor:
-    """M:2633-2648: apply the stashed mask, rebuild the mask at the ACTUAL length, keep free
-    positions, reshape to [1, B, K, F]."""
+def undelay(cfg: ParlerTTSConfig, raw_ids: torch.Tensor, pattern: torch.Tensor, num_return_sequences: int = 1) -> torch.Tensor:
+    """M:2633-2648: apply the stashed mask, rebuild the mask at the ACTUAL length (from the start ids of every row, a
+    regular pattern also under num_return_sequences), keep free positions, reshape to [1, B, K, -1] with the ORIGINAL
+    batch size (M:2645: n * F columns per utterance under num_return_sequences = n)."""
     dec = cfg.decoder
     K = dec.num_codebooks
     out = apply_delay_pattern_mask(raw_ids, pattern)
     start = torch.full((raw_ids.shape[0], 1), dec.bos_token_id, dtype=torch.long)
     _, m = build_delay_pattern_mask(start, dec.bos_token_id, dec.pad_token_id, out.shape[1], K)
     keep = (m != dec.bos_token_id) & (m != dec.pad_token_id)
-    return out[keep].reshape(raw_ids.shape[0] // K, K, -1)[None, ...]
+    return out[keep].reshape(raw_ids.shape[0] // (K * num_return_sequences), K, -1)[None, ...]
 
 
 # ----------------------------------------------------------------------------------------------

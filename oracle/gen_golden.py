@@ -90,12 +90,13 @@ _models = {}
 
 
 def run_case(name, cfg, sd_kw, B, T, P, L, seed_in, ragged=False, pass_prompt_mask=False, record=0,
-             min_margin=0.0, _max_attempts=40, **gen):
+             min_margin=0.0, _max_attempts=40, cfg_kw=None, **gen):
     """``min_margin``: input seeds are scanned (seed_in, seed_in+1000, ...) until every kept greedy
     argmax of the reference run has a top-2 gap above it, so that bit-exact token parity is a fair
     demand on an implementation whose fp32 sums are ordered differently."""
     key = (id(cfg), json.dumps(sd_kw, sort_keys=True))
     if key not in _models:
+        _models.clear()
         sd = synthetic_state_dict(cfg, parts=("text_encoder", "decoder"), **sd_kw)
         _models[key] = ref_shim.build_reference_model(cfg, sd)
     model = _models[key]
@@ -113,7 +114,9 @@ def run_case(name, cfg, sd_kw, B, T, P, L, seed_in, ragged=False, pass_prompt_ma
     print(f"  {name}: seed_in={seed_in} free-min margin {fm:.3e}")
     arrays = dict(desc=desc, amask=amask, prompt=prompt, pmask=pmask, has_pmask=int(use_pmask is not None),
                   max_length=L, free_min_margin=fm, **{k: v for k, v in r.items()})
-    arrays["meta"] = json.dumps(dict(sd_kw=sd_kw, B=B, T=T, P=P, L=L, seed_in=seed_in, ragged=ragged,
+    if isinstance(record, (set, frozenset)):
+        arrays["logit_steps"] = np.array(sorted(record))
+    arrays["meta"] = json.dumps(dict(sd_kw=sd_kw, cfg_kw=cfg_kw, B=B, T=T, P=P, L=L, seed_in=seed_in, ragged=ragged,
                                      gen={k: (v if not isinstance(v, dict) else "forced") for k, v in gen.items()
                                           if k != "generator" and not isinstance(v, torch.Tensor)}))
     for k in ("decoder_input_ids", "decoder_attention_mask"):
@@ -226,8 +229,87 @@ def causal_case():
          meta=json.dumps(dict(sd_kw=sd_kw, B=B, T=T, P=P, L=L, seed_in=seed_in)), **r)
 
 
+def long_cases():
+    """Parity at depth: the REAL reference run over the benchmark's full horizon on the tiny shape
+    (L = 2580: 41 KV pages, positions up to 2584) and over 512 columns on the mini_v0.1 shape.  Kept per case: raw
+    ids, the top-2 margin of every argmax, and the logits of a sample of steps (first, page boundaries, > 1024, > 2048,
+    the last 8).  Tests teacher-force the engine along the raw ids, so one sub-margin argmax cannot derail the rest."""
+    cfg_kw = dict(max_positions=2816)
+    tiny = tiny_config(**cfg_kw)
+    kw = dict(seed=11, never_eos=True, ln_jitter=0.1)
+    L = 2580
+    steps = set(range(0, 6)) | set(range(58, L - 1, 128)) | {1023, 1024, 1025, 2047, 2048, 2049} | set(range(L - 9, L - 1))
+    run_case("tinylong_greedy", tiny, kw, B=2, T=9, P=5, L=L, seed_in=500, record=frozenset(steps), cfg_kw=cfg_kw)
+    mini = mini_v01_config()
+    kwm = dict(seed=21, never_eos=True, ln_jitter=0.0)
+    L = 512
+    steps = {0, 1, 57, 58, 121, 249, 250, 377, 441} | set(range(L - 7, L - 1))
+    run_case("minilong_greedy", mini, kwm, B=2, T=12, P=6, L=L, seed_in=11300, record=frozenset(steps))
+
+
+def bf16_long_case():
+    """The engine-numerics (bf16 mode) restatement, oracle/cpu_ref_bf16.py, teacher-forced along the REFERENCE's raw ids of
+    minilong_greedy (512 columns at mini_v0.1 size are minutes of CPU, too slow for the GPU box's test run): logits of the
+    same sampled steps, its own argmax of every step and the top-2 margin of those argmaxes.  Does not need /root/reference."""
+    from oracle import cpu_ref_bf16
+    from tests.helpers import case_inputs, load_case, state_dict_for
+
+    f, meta = load_case("minilong_greedy")
+    cfg, sd = state_dict_for("minilong_greedy", meta)
+    desc, amask, prompt, pmask = case_inputs(f)
+    steps = set(int(x) for x in f["logit_steps"])
+    gold = torch.from_numpy(f["raw_ids"])
+    L = int(f["max_length"])
+    out = {}
+    for tag, acc64 in (("", False), ("_acc64", True)):
+        dec = cpu_ref_bf16.EngineBf16Decoder(cfg, sd, acc64=acc64)
+        margins = []
+        orig = dec.logits
+
+        def logits_and_margin(x, orig=orig, margins=margins):
+            lg = orig(x)
+            t2 = torch.topk(lg, 2, dim=-1)[0]
+            margins.append(t2[:, 0] - t2[:, 1])
+            return lg
+
+        dec.logits = logits_and_margin
+        r = cpu_ref_bf16.generate_ids(cfg, sd, torch.from_numpy(f["enc_t5"]), amask, prompt, pmask, L, forced=gold,
+                                      record=steps, decoder=dec)
+        out["step_logits" + tag] = r["step_logits"]
+        out["own" + tag] = r["own"]
+        out["margins" + tag] = torch.stack(margins)
+        out["logit_steps"] = r["logit_steps"]
+        del dec
+    # the second evaluation accumulates every product and statistic in fp64: the distance between the two is the
+    # restatement's own re-association spread, the yardstick of the bf16 GPU test
+    print("  re-association spread of the restatement:", float((out["step_logits"] - out["step_logits_acc64"]).abs().max()))
+    save("minilong_greedy_bf16", **out)
+
+
+def nrs_case():
+    """num_return_sequences = 2 under sampling (M:2600-2606): the reference's own expansion (third-party
+    `_expand_inputs_for_generation`) of the id rows, the kwargs and the stashed delay pattern; teacher-forced fixture
+    along the reference's sampled path like tiny_sample."""
+    tiny = tiny_config()
+    kw = dict(seed=11, never_eos=True, ln_jitter=0.1)
+    g = torch.Generator().manual_seed(2025)
+    run_case("tiny_sample_nrs2", tiny, kw, B=2, T=9, P=5, L=22, seed_in=106, record=64, do_sample=True,
+             temperature=0.7, top_k=50, generator=g, num_return_sequences=2)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-long" in sys.argv:
+        torch.set_num_threads(8)
+        long_cases()
+        return
+    if "--only-bf16" in sys.argv:
+        torch.set_num_threads(8)
+        bf16_long_case()
+        return
+    if "--only-nrs" in sys.argv:
+        nrs_case()
+        return
     if "--only-causal" in sys.argv:
         causal_case()
         return

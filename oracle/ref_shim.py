@@ -114,11 +114,12 @@ def build_reference_model(cfg, state_dict):
 def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, prompt_attention_mask,
                            max_length, do_sample=False, temperature=1.0, top_k=50, guidance_scale=None,
                            generator=None, record_logits=0, forced_tokens=None, decoder_input_ids=None,
-                           decoder_attention_mask=None):
+                           decoder_attention_mask=None, num_return_sequences=1):
     """Drive the REAL reference ``forward`` (M:1927) + ``prepare_inputs_for_generation`` (M:2081) +
     ``build/apply_delay_pattern_mask`` with the third-party greedy/sample step restated in a few lines
     (transformers 4.3x ``greedy_search``/``sample`` no longer exist).
-    Then the un-delay of M:2633-2648 using the reference's own functions."""
+    Then the un-delay of M:2633-2648 using the reference's own functions.
+    ``record_logits``: an int n (the first n steps) or a set of step indices (long runs keep a sample)."""
     from transformers.modeling_outputs import BaseModelOutput
 
     dec = model.decoder.config
@@ -152,7 +153,17 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
         if "decoder_attention_mask" in mk:
             kw["decoder_attention_mask"] = mk["decoder_attention_mask"]
     ids, pattern = model.decoder.build_delay_pattern_mask(ids, dec.bos_token_id, dec.pad_token_id, max_length)
-    unf = torch.ones(B * K, dtype=torch.long)
+    if num_return_sequences > 1:
+        # M:2600-2606: the third-party helper the reference calls (a static method, still present in transformers 5.15)
+        # repeat_interleaves the id rows and every tensor kwarg, the stashed delay pattern included
+        from transformers import GenerationMixin
+
+        ids, kw = GenerationMixin._expand_inputs_for_generation(
+            expand_size=num_return_sequences, is_encoder_decoder=True, input_ids=ids,
+            decoder_delay_pattern_mask=pattern, **kw)
+        pattern = kw.pop("decoder_delay_pattern_mask")
+    start_ids = ids[:, :1].clone() if decoder_input_ids is None else None
+    unf = torch.ones(ids.shape[0], dtype=torch.long)
     past = None
     step_logits, margins, step = [], [], 0
     while True:
@@ -163,7 +174,7 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
         if use_cfg:
             n = logits.shape[0] // 2
             logits = logits[n:] + (logits[:n] - logits[n:]) * guidance_scale
-        if step < record_logits:
+        if (step in record_logits) if isinstance(record_logits, (set, frozenset)) else (step < record_logits):
             step_logits.append(logits.clone())
         if do_sample:
             s = logits / temperature if temperature != 1.0 else logits
@@ -188,10 +199,10 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
             break
     # M:2633-2648
     out_ids = model.decoder.apply_delay_pattern_mask(ids, pattern)
-    start = torch.full((B * K, 1), dec.bos_token_id, dtype=torch.long)
+    start = torch.full((ids.shape[0], 1), dec.bos_token_id, dtype=torch.long)     # M:2637 passes the (expanded) start ids
     _, m = model.decoder.build_delay_pattern_mask(start, dec.bos_token_id, dec.pad_token_id, out_ids.shape[1])
     keep = (m != dec.bos_token_id) & (m != dec.pad_token_id)
-    codes = out_ids[keep].reshape(B, K, -1)
+    codes = out_ids[keep].reshape(B, K, -1)                                         # M:2645: the ORIGINAL batch size
     res = {"raw_ids": ids, "pattern": pattern, "codes": codes, "enc_t5": enc_t5}
     if step_logits:
         res["step_logits"] = torch.stack(step_logits)

@@ -11,14 +11,14 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libparler_tts_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 # every symbol include/parler_tts_hip.h declares (tests check the export table against this list)
 EXPORTS = [
     "ptts_last_error", "ptts_abi_version", "ptts_create", "ptts_destroy", "ptts_load_tensor", "ptts_weights_ready",
     "ptts_t5_encode", "ptts_dac_decode", "ptts_dac_encode", "ptts_set_prompt_embeds", "ptts_set_decoder_mask", "ptts_prefill", "ptts_decode_steps", "ptts_forward_step", "ptts_select_step", "ptts_get_state", "ptts_last_logits",
-    "ptts_set_block_table", "ptts_pool_info", "ptts_set_forced_tokens", "ptts_profile_read", "ptts_test_gemm",
+    "ptts_set_block_table", "ptts_pool_info", "ptts_set_forced_tokens", "ptts_set_forced_sequence", "ptts_profile_read", "ptts_test_gemm",
     "ptts_debug_stop_after", "ptts_debug_buffer",
 ]
 
@@ -41,7 +41,12 @@ class PttsConfig(C.Structure):
 
 class PttsSampling(C.Structure):
     _fields_ = [("do_sample", C.c_int32), ("temperature", C.c_float), ("top_k", C.c_int32),
-                ("guidance_scale", C.c_float), ("seed", C.c_uint64), ("top_p", C.c_float)]
+                ("guidance_scale", C.c_float), ("seed", C.c_uint64), ("top_p", C.c_float),
+                ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32), ("eos_free_until", C.c_int32)]
+
+    def __init__(self, do_sample=0, temperature=1.0, top_k=0, guidance_scale=1.0, seed=0, top_p=1.0, eos_token_id=-1,
+                 pad_token_id=-1, eos_free_until=0):
+        super().__init__(do_sample, temperature, top_k, guidance_scale, seed, top_p, eos_token_id, pad_token_id, eos_free_until)
 
 
 class PttsState(C.Structure):
@@ -96,6 +101,7 @@ def load_library() -> C.CDLL:
     lib.ptts_set_block_table.argtypes = [vp, C.POINTER(C.c_int32), i32, i32]
     lib.ptts_pool_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.ptts_set_forced_tokens.argtypes = [vp, i64p, i32]
+    lib.ptts_set_forced_sequence.argtypes = [vp, vp, vp]
     lib.ptts_profile_read.argtypes = [vp, C.POINTER(PttsProfile), i32]
     lib.ptts_debug_stop_after.argtypes = [vp, i32]
     lib.ptts_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int64)]

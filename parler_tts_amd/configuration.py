@@ -228,6 +228,7 @@ class GenerationConfig(_ConfigBase):
         self.max_length = kwargs.pop("max_length", 2580)
         self.max_new_tokens = kwargs.pop("max_new_tokens", None)
         self.min_length = kwargs.pop("min_length", 0)
+        self.min_new_tokens = kwargs.pop("min_new_tokens", None)
         self.do_sample = kwargs.pop("do_sample", True)
         self.temperature = kwargs.pop("temperature", 1.0)
         self.top_k = kwargs.pop("top_k", 50)
@@ -252,7 +253,7 @@ class GenerationConfig(_ConfigBase):
         return d
 
     _FIELDS = (
-        "max_length max_new_tokens min_length do_sample temperature top_k top_p num_beams num_beam_groups "
+        "max_length max_new_tokens min_length min_new_tokens do_sample temperature top_k top_p num_beams num_beam_groups "
         "num_return_sequences guidance_scale pad_token_id bos_token_id eos_token_id decoder_start_token_id "
         "use_cache return_dict_in_generate output_scores seed"
     ).split()
@@ -274,6 +275,28 @@ class GenerationConfig(_ConfigBase):
             raise ValueError("`temperature` must be strictly positive when sampling")
         if self.top_k is not None and self.top_k < 0:
             raise ValueError("`top_k` must be >= 0")
+        # fields of a generation_config.json this engine does not act on: bookkeeping keys are ignored, a generation
+        # parameter left at its neutral HF default is ignored, anything else would silently change the output -> refuse
+        for k, v in self._extra.items():
+            if k in self._INERT or k.startswith("output_"):
+                continue
+            if k in self._NEUTRAL and (v is None or v == self._NEUTRAL[k]):
+                continue
+            raise NotImplementedError(f"generation_config field `{k}` = {v!r} is not served by this engine "
+                                      "(it would change the generated tokens in the reference)")
+
+    _INERT = {"transformers_version", "_from_model_config", "_commit_hash", "_original_object_hash", "return_legacy_cache",
+              "cache_implementation", "cache_config", "use_cache", "max_time", "generation_kwargs", "is_assistant",
+              "return_dict_in_generate", "low_memory", "watermarking_config", "token_healing", "compile_config",
+              "disable_compile", "trust_remote_code", "stop_strings"}
+    _NEUTRAL = {"repetition_penalty": 1.0, "encoder_repetition_penalty": 1.0, "no_repeat_ngram_size": 0,
+                "encoder_no_repeat_ngram_size": 0, "bad_words_ids": None, "force_words_ids": None, "typical_p": 1.0,
+                "epsilon_cutoff": 0.0, "eta_cutoff": 0.0, "min_p": None, "diversity_penalty": 0.0, "length_penalty": 1.0,
+                "early_stopping": False, "penalty_alpha": None, "renormalize_logits": False, "constraints": None,
+                "forced_bos_token_id": None, "forced_eos_token_id": None, "remove_invalid_values": False,
+                "exponential_decay_length_penalty": None, "suppress_tokens": None, "begin_suppress_tokens": None,
+                "forced_decoder_ids": None, "sequence_bias": None, "num_assistant_tokens": None, "dola_layers": None,
+                "prompt_lookup_num_tokens": None, "temperature_last_layer": None, "top_h": None}
 
 
 class ParlerTTSConfig(_ConfigBase):
@@ -358,14 +381,14 @@ def scaled_config() -> ParlerTTSConfig:
 
 
 def tiny_config(num_codebooks: int = 4, hidden: int = 128, layers: int = 2, heads: int = 2, ffn: int = 256,
-                codebook_size: int = 64, enc_d: int = 64) -> ParlerTTSConfig:
+                codebook_size: int = 64, enc_d: int = 64, max_positions: int = 256) -> ParlerTTSConfig:
     """A toy architecture with the same structure, for second-scale CPU tests.
 
     hidden must be a multiple of 64 (head_dim is 64 as in every released Parler-TTS decoder).
     """
     dec = ParlerTTSDecoderConfig(
         vocab_size=codebook_size + 64,
-        max_position_embeddings=256,
+        max_position_embeddings=max_positions,
         num_hidden_layers=layers,
         ffn_dim=ffn,
         num_attention_heads=heads,

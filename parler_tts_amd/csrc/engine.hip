@@ -132,6 +132,8 @@ struct ptts_engine {
     int *tok_in = nullptr, *unfinished = nullptr;
     long long* force = nullptr;
     bool use_force = false;
+    const long long* force_seq = nullptr;   // ptts_set_forced_sequence
+    long long* own_choice = nullptr;
     StepState* state = nullptr;
     // DAC decoder (codec): conv0, per block {convT, 3 x (conv7, conv1)}, final conv
     std::vector<ConvLayer> dac;
@@ -457,7 +459,10 @@ int run_select_half(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
     sa.logits = e->logits; sa.rows = e->B * c.codebooks; sa.V = e->Vp; sa.vocab = c.vocab; sa.L = e->L; sa.state = e->state;
     sa.raw_ids = e->raw_ids; sa.pattern = e->pattern; sa.unfinished = e->unfinished;
     sa.tok_in = e->tok_in; sa.force = e->use_force ? e->force : nullptr; sa.probs = e->probs;
-    sa.pad = c.pad_token_id; sa.eos = c.eos_token_id; sa.do_sample = sp.do_sample; sa.top_k = sp.top_k;
+    sa.force_seq = e->force_seq; sa.own = e->own_choice; sa.eos_free_until = sp.eos_free_until;
+    sa.pad = sp.pad_token_id >= 0 ? sp.pad_token_id : c.pad_token_id;
+    sa.eos = sp.eos_token_id >= 0 ? sp.eos_token_id : (sp.eos_token_id == -1 ? c.eos_token_id : -1);   // <= -2: no EOS criterion
+    sa.do_sample = sp.do_sample; sa.top_k = sp.top_k;
     sa.temperature = sp.temperature; sa.guidance = sp.guidance_scale; sa.seed = sp.seed;
     sa.top_p = (sp.top_p > 0.f && sp.top_p < 1.f) ? sp.top_p : 1.0f;
     HIP_TRY(select_launch(sa, s));
@@ -480,7 +485,8 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
 
 bool same_sampling(const ptts_sampling& a, const ptts_sampling& b) {
     return a.do_sample == b.do_sample && a.temperature == b.temperature && a.top_k == b.top_k &&
-           a.guidance_scale == b.guidance_scale && a.seed == b.seed && a.top_p == b.top_p;
+           a.guidance_scale == b.guidance_scale && a.seed == b.seed && a.top_p == b.top_p &&
+           a.eos_token_id == b.eos_token_id && a.pad_token_id == b.pad_token_id && a.eos_free_until == b.eos_free_until;
 }
 
 void drop_graph(ptts_engine* e) {
@@ -706,8 +712,6 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     if (cfg->hidden <= 0 || cfg->hidden % 64 != 0 || cfg->heads * PTTS_HEAD_DIM != cfg->hidden)
         return fail(PTTS_E_UNSUPPORTED, "hidden=%d heads=%d: head_dim must be 64", cfg->hidden, cfg->heads);
     if (cfg->ffn % 32 != 0 || cfg->enc_hidden % 32 != 0) return fail(PTTS_E_UNSUPPORTED, "ffn / enc_hidden must be multiples of 32");
-    if (cfg->hidden > (cfg->dtype == PTTS_DTYPE_BF16 ? 2048 : 1024))
-        return fail(PTTS_E_UNSUPPORTED, "hidden=%d exceeds the LDS-resident LayerNorm row (2048 bf16 / 1024 f32)", cfg->hidden);
     if (cfg->codebooks <= 0 || cfg->codebooks > 32) return fail(PTTS_E_UNSUPPORTED, "codebooks must be in [1, 32]");
     if (cfg->max_batch <= 0 || cfg->max_length <= 1 || cfg->max_desc_len <= 0 || cfg->max_prompt_len < 0)
         return fail(PTTS_E_INVALID, "bad limits");
@@ -726,8 +730,16 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->layers.resize(cfg->layers);
     e->t5.resize(cfg->t5_layers > 0 ? cfg->t5_layers : 0);
     e->no_graph = getenv("PTTS_NO_GRAPH") != nullptr;
-    e->fold_ln = cfg->dtype == PTTS_DTYPE_BF16;
+    // LayerNorm rows wider than the LDS-resident stage (2048 bf16 / 1024 f32 elements; BASELINE configs[4] has 1536) can
+    // only take the folded form, which reads the rows as fragments and has no width limit (M:402-413 has none either)
+    const bool wide_rows = cfg->hidden > (cfg->dtype == PTTS_DTYPE_BF16 ? 2048 : 1024);
+    e->fold_ln = cfg->dtype == PTTS_DTYPE_BF16 || wide_rows;
     if (const char* v = getenv("PTTS_LN_FOLD")) e->fold_ln = atoi(v) != 0;
+    if (wide_rows && !e->fold_ln) {
+        delete e;
+        return fail(PTTS_E_UNSUPPORTED, "hidden=%d needs the folded LayerNorm (PTTS_LN_FOLD=0 keeps rows of <= %d elements)",
+                    cfg->hidden, cfg->dtype == PTTS_DTYPE_BF16 ? 2048 : 1024);
+    }
     e->no_page_kernel = getenv("PTTS_ATTN_NO_PAGE_KERNEL") != nullptr;
     e->lookahead = e->fold_ln;      // look-ahead cross-q rides on the folded LayerNorm (PTTS_LOOKAHEAD=0 switches it off)
     if (const char* v = getenv("PTTS_LOOKAHEAD")) e->lookahead = atoi(v) != 0;
@@ -1251,6 +1263,14 @@ int ptts_set_forced_tokens(ptts_engine* e, const int64_t* tokens_host, int32_t r
     if (rows != e->B * e->cfg.codebooks) return fail(PTTS_E_INVALID, "rows must be B*K");
     HIP_TRY(hipMemcpy(e->force, tokens_host, sizeof(long long) * rows, hipMemcpyHostToDevice));
     e->use_force = true;
+    return PTTS_OK;
+}
+
+int ptts_set_forced_sequence(ptts_engine* e, const int64_t* forced_ids, int64_t* own_choice) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    e->force_seq = (const long long*)forced_ids;
+    e->own_choice = forced_ids ? (long long*)own_choice : nullptr;
+    drop_graph(e);       // the pointers are baked into the captured select node
     return PTTS_OK;
 }
 

@@ -26,6 +26,9 @@ struct SelectArgs {
     int* unfinished = nullptr;           // [rows]
     int* tok_in = nullptr;               // [rows (x2)]
     const long long* force = nullptr;    // [rows] or null
+    const long long* force_seq = nullptr;   // [rows][L] or null: column cur_len overrides the choice where >= 0
+    long long* own = nullptr;               // [rows][L] or null: the step's own choice goes to column cur_len
+    int eos_free_until = 0;                 // score[eos] = -inf while cur_len < this (MinLength / MinNewTokens processors)
     float* probs = nullptr;              // [rows][V] or null
     int pad = 0, eos = 0;
     int do_sample = 0, top_k = 0;

@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     for (int v = tid; v < V; v += 256) {
         float s = lg[v];
         if (ug) { float u = ug[v]; s = u + (s - u) * a.guidance; }
+        // MinLength / MinNewTokensLength processors run on the raw scores, before the warpers (third-party loop order)
+        if (v == a.eos && cur < a.eos_free_until) s = -INFINITY;
         if (a.do_sample && a.temperature != 1.0f) s = s / a.temperature;
         sv[v] = s;
     }
@@ -358,7 +360,9 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 
     if (tid == 0) {
         long long tok = choice;
+        if (a.own) a.own[(size_t)row * a.L + cur] = tok;
         if (a.force && a.force[row] >= 0) tok = a.force[row];   // teacher forcing (tests)
+        if (a.force_seq) { const long long f = a.force_seq[(size_t)row * a.L + cur]; if (f >= 0) tok = f; }
         const int unf = a.unfinished[row];
         long long nxt = unf ? tok : (long long)a.pad;
         a.raw_ids[(size_t)row * a.L + cur] = nxt;

@@ -75,8 +75,8 @@ class HipEngine:
         self.codec_only = codec_only
         self.has_codec = any(k.startswith("audio_encoder.model.decoder.") for k in state_dict)
         self.has_codec_encoder = False
-        if codec_only:
-            with_t5 = False
+        if codec_only or not any(k.startswith("text_encoder.") for k in state_dict):
+            with_t5 = False          # no text-encoder tensors: callers pass `encoder_outputs`
         c = _hip.PttsConfig()
         c.abi_version = _hip.ABI_VERSION
         c.dtype = _hip.DTYPE_BF16 if dtype == "bf16" else _hip.DTYPE_F32
@@ -157,8 +157,9 @@ class HipEngine:
         ids = input_ids.to(self.device, torch.int64).contiguous()
         mask = attention_mask.to(self.device, torch.int32).contiguous()
         out = torch.empty(B, T, t5.d_model, device=self.device, dtype=torch.float32)
-        _hip.check(self.lib.ptts_t5_encode(self.handle, B, T, _ptr(ids), _ptr(mask), _ptr(table), _ptr(out), _stream()))
-        torch.cuda.current_stream().synchronize()  # `table`/`ids` are temporaries
+        with torch.cuda.device(self.device):       # streams, lazy allocations and launches follow the CURRENT device
+            _hip.check(self.lib.ptts_t5_encode(self.handle, B, T, _ptr(ids), _ptr(mask), _ptr(table), _ptr(out), _stream()))
+            torch.cuda.current_stream().synchronize()  # `table`/`ids` are temporaries
         return out
 
     def dac_decode(self, codes: torch.Tensor) -> torch.Tensor:
@@ -171,8 +172,9 @@ class HipEngine:
         if codes.numel() and (int(codes.max()) >= self.cfg.audio_encoder.codebook_size or int(codes.min()) < 0):
             raise IndexError("index out of range in self: codec ids must be in [0, codebook_size)")
         out = torch.empty(B, F * hop, device=self.device, dtype=torch.float32)
-        _hip.check(self.lib.ptts_dac_decode(self.handle, B, F, _ptr(codes), _ptr(out), _stream()))
-        torch.cuda.current_stream().synchronize()   # `codes` may be a temporary
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.ptts_dac_decode(self.handle, B, F, _ptr(codes), _ptr(out), _stream()))
+            torch.cuda.current_stream().synchronize()   # `codes` may be a temporary
         return out
 
     def dac_encode(self, audio: torch.Tensor) -> torch.Tensor:
@@ -185,8 +187,9 @@ class HipEngine:
             raise ValueError(f"audio prompt of {T} samples is shorter than one codec frame ({a.hop_length})")
         audio = audio.to(self.device, torch.float32).contiguous()
         codes = torch.empty(B, a.num_codebooks, T // a.hop_length, device=self.device, dtype=torch.int64)
-        _hip.check(self.lib.ptts_dac_encode(self.handle, B, T, _ptr(audio), _ptr(codes), _stream()))
-        torch.cuda.current_stream().synchronize()   # `audio` may be a temporary
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.ptts_dac_encode(self.handle, B, T, _ptr(audio), _ptr(codes), _stream()))
+            torch.cuda.current_stream().synchronize()   # `audio` may be a temporary
         return codes
 
     def prefill(self, B, B_eff, enc_states, attention_mask, prompt_ids, prompt_mask, pattern, raw_ids, start_len,
@@ -251,6 +254,12 @@ class HipEngine:
         t = tokens.to("cpu", torch.int64).contiguous()
         arr = (C.c_int64 * t.numel())(*t.tolist())
         _hip.check(self.lib.ptts_set_forced_tokens(self.handle, arr, t.numel()))
+
+    def set_forced_sequence(self, forced: Optional[torch.Tensor], own: Optional[torch.Tensor] = None) -> None:
+        """Device-side teacher forcing (ptts_set_forced_sequence): `forced` [B*K, L] int64 on the engine's device
+        (values < 0 leave a column alone), `own` receives the engine's own choices.  The caller keeps both alive."""
+        self._forced_keep = (forced, own)
+        _hip.check(self.lib.ptts_set_forced_sequence(self.handle, _ptr(forced), _ptr(own)))
 
     def set_block_table(self, table: torch.Tensor) -> None:
         t = table.to("cpu", torch.int32).contiguous()
@@ -434,6 +443,12 @@ class ParlerTTSForConditionalGeneration:
     def generate(self, inputs: Optional[torch.Tensor] = None, generation_config: Optional[GenerationConfig] = None,
                  logits_processor=None, stopping_criteria=None, synced_gpus: Optional[bool] = None, streamer=None,
                  **kwargs):
+        # every stream handle, lazy allocation and launch below follows the CURRENT device: make it the model's
+        with torch.cuda.device(self.device):
+            return self._generate(inputs, generation_config, logits_processor, stopping_criteria, synced_gpus, streamer,
+                                  **kwargs)
+
+    def _generate(self, inputs, generation_config, logits_processor, stopping_criteria, synced_gpus, streamer, **kwargs):
         cfgm, dec = self.config, self.config.decoder
         K = dec.num_codebooks
         # 1. generation config (M:2416-2422)
@@ -536,8 +551,20 @@ class ParlerTTSForConditionalGeneration:
                              "Ensure that beam search is de-activated by setting `num_beams=1` and `num_beam_groups=1`.")
         if greedy and gen.num_return_sequences > 1:
             raise ValueError(f"num_return_sequences has to be 1 when doing greedy search, but is {gen.num_return_sequences}.")
-        if sample and gen.num_return_sequences > 1:
-            raise NotImplementedError("num_return_sequences > 1: repeat the batch rows instead")
+        nrs = int(gen.num_return_sequences) if sample else 1
+        # EOS suppression of the default processors (third-party `_get_logits_processor`, called at M:2561-2567)
+        eos_free_until = 0
+        if gen.eos_token_id is not None:
+            if gen.min_length is not None and gen.min_length > 0:
+                eos_free_until = int(gen.min_length)                                   # MinLengthLogitsProcessor
+            if gen.min_new_tokens is not None and gen.min_new_tokens > 0:              # MinNewTokensLengthLogitsProcessor
+                eos_free_until = max(eos_free_until, ids.shape[-1] + int(gen.min_new_tokens))
+        if eos_free_until and use_cfg:
+            # the reference runs these processors BEFORE its guidance processor (user / guidance processors are merged
+            # behind the default ones): eos is -inf in both halves and uncond + (cond - uncond) * scale makes it NaN,
+            # which argmax then picks and multinomial rejects.  Not reproduced.
+            raise NotImplementedError("min_length / min_new_tokens together with guidance_scale > 1 yields NaN scores in "
+                                      "the reference (-inf - -inf in the guidance combine)")
 
         # id ranges: the reference fails with an IndexError in its embedding lookups; the gather kernels must never be handed
         # an id outside their tables
@@ -557,7 +584,7 @@ class ParlerTTSForConditionalGeneration:
             _in_range("input_ids", input_ids, cfgm.text_encoder.vocab_size)
         _in_range("prompt_input_ids", prompt_ids, cfgm.vocab_size)
         _in_range("decoder_input_ids", ids, dec.vocab_size + 1)       # embed_tokens has vocab_size + 1 rows (M:769-773)
-        eng = self.engine(B_eff, T, P, L)
+        eng = self.engine(B_eff * nrs, T, P, L)
         import time as _time
 
         def _tick():
@@ -581,31 +608,56 @@ class ParlerTTSForConditionalGeneration:
             pids = None if pids is None else pids.repeat(2, 1)
             pmask32 = None if pmask32 is None else pmask32.repeat(2, 1)
             pemb = None if pemb is None else pemb.repeat(2, 1, 1)                            # M:2115-2116
+        # delay pattern (M:2530-2537): built for the B utterances, BEFORE any num_return_sequences expansion
+        ids, pattern = build_delay_pattern_mask(ids, gen.bos_token_id, gen.pad_token_id, L, K)
+        if streamer is not None:
+            streamer.put(ids.cpu())                                                          # M:2540-2541
+        dmask32 = None
+        if dec_mask is not None:
+            dmask32 = dec_mask.to(torch.int32)
+            dmask32 = (dmask32.repeat(2, 1) if use_cfg else dmask32)                         # M:2112-2113
+        B_gen = B
+        if nrs > 1:
+            # `_expand_inputs_for_generation` (third party, called at M:2600-2606): repeat_interleave along dim 0 of the id
+            # rows [B*K, s] AND of every tensor kwarg, the stashed delay pattern [B*K, L] included.  Row (b*K + k)*n + j is
+            # then read by the decoder's reshape(-1, K, len) (M:823) as codebook ((b*K + k)*n + j) % K of utterance
+            # ((b*K + k)*n + j) // K, under the delay pattern of codebook k: reproduced as is (the engine takes any pattern).
+            rep = lambda t: None if t is None else t.repeat_interleave(nrs, dim=0)
+            enc, amask32, pids, pmask32, pemb, dmask32 = rep(enc), rep(amask32), rep(pids), rep(pmask32), rep(pemb), rep(dmask32)
+            ids, pattern = rep(ids), rep(pattern)
+            B_gen, B_eff = B * nrs, B_eff * nrs
         pemb = None if pemb is None else pemb.contiguous()
+        dmask32 = None if dmask32 is None else dmask32.contiguous()
         enc = enc.contiguous()
         amask32 = amask32.contiguous()
         pids = None if pids is None else pids.contiguous()
         pmask32 = None if pmask32 is None else pmask32.contiguous()
-        # delay pattern (M:2530-2537)
-        ids, pattern = build_delay_pattern_mask(ids, gen.bos_token_id, gen.pad_token_id, L, K)
         pattern = pattern.contiguous()
         start_len = ids.shape[1]
-        raw_ids = torch.full((B * K, L), gen.pad_token_id, dtype=torch.long, device=dev)
+        raw_ids = torch.full((B_gen * K, L), gen.pad_token_id, dtype=torch.long, device=dev)
         raw_ids[:, :start_len] = ids
-        if streamer is not None:
-            streamer.put(ids.cpu())                                                          # M:2540-2541
         sp = _hip.PttsSampling()
         sp.do_sample = 1 if sample else 0
         sp.temperature = float(gen.temperature if gen.temperature is not None else 1.0)
         sp.top_k = int(gen.top_k or 0)
         sp.guidance_scale = float(gen.guidance_scale) if use_cfg else 1.0
         sp.top_p = float(gen.top_p) if (gen.top_p is not None and 0.0 < gen.top_p < 1.0) else 1.0
-        sp.seed = int(gen.seed if gen.seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        dmask32 = None
-        if dec_mask is not None:
-            dmask32 = dec_mask.to(torch.int32)
-            dmask32 = (dmask32.repeat(2, 1) if use_cfg else dmask32).contiguous()            # M:2112-2113
-        eng.prefill(B, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len, prompt_embeds=pemb, dec_mask=dmask32)
+        if gen.seed is not None:
+            seed = int(gen.seed)
+        elif sample:
+            # like torch.multinomial in the reference, an unseeded call consumes the global CPU generator: two calls draw
+            # different streams, torch.manual_seed(s) reproduces a run
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        else:
+            seed = 0
+        sp.seed = seed & 0xFFFFFFFFFFFFFFFF
+        self.last_seed = sp.seed
+        sp.eos_token_id = -1 if gen.eos_token_id is None else int(gen.eos_token_id)
+        sp.pad_token_id = -1 if gen.pad_token_id is None else int(gen.pad_token_id)
+        if gen.eos_token_id is None:
+            sp.eos_token_id = -2          # no EOS criterion: nothing latches (the third-party loop skips the check)
+        sp.eos_free_until = eos_free_until
+        eng.prefill(B_gen, B_eff, enc, amask32, pids, pmask32, pattern, raw_ids, start_len, prompt_embeds=pemb, dec_mask=dmask32)
         t_dec = _tick()
         # ---- the hot loop: state lives on the device, the host only polls for "all rows finished" ----
         remaining = L - start_len
@@ -615,7 +667,7 @@ class ParlerTTSForConditionalGeneration:
             # them between the forward half and the selection half, in the order of the third-party loop
             # (processors on [B*K, vocab] scores after the guidance combine, then the warpers inside the select kernel)
             V = dec.vocab_size
-            n = B * K
+            n = B_gen * K
             while remaining > 0:
                 eng.forward_step()
                 st = eng.state()
@@ -667,7 +719,9 @@ class ParlerTTSForConditionalGeneration:
         self.last_raw_ids = raw_ids[:, :L_out]
         # ---- un-delay (M:2633-2648): integer bookkeeping on the device tensors ----
         out_ids = apply_delay_pattern_mask(raw_ids[:, :L_out], pattern)
-        start = torch.full((B * K, 1), start_tok, dtype=torch.long, device=dev)
+        # M:2637 rebuilds the mask from the (expanded) start ids: a REGULAR pattern over B_gen * K rows, then M:2645 reshapes
+        # with the ORIGINAL batch size - under num_return_sequences = n every utterance ends up with n * F columns
+        start = torch.full((B_gen * K, 1), start_tok, dtype=torch.long, device=dev)
         _, m = build_delay_pattern_mask(start, gen.bos_token_id, gen.pad_token_id, L_out, K)
         keep = (m != gen.bos_token_id) & (m != gen.pad_token_id)
         output_ids = out_ids[keep].reshape(B, K, -1)[None, ...]

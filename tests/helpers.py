@@ -13,8 +13,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _sd_cache = {}
 
 
-def config_for(name):
-    return mini_v01_config() if name.startswith("mini") or name == "dac_mini" else tiny_config()
+def config_for(name, meta=None):
+    if name.startswith("mini") or name == "dac_mini":
+        return mini_v01_config()
+    return tiny_config(**((meta or {}).get("cfg_kw") or {}))
 
 
 def load_case(name):
@@ -24,8 +26,8 @@ def load_case(name):
 
 
 def state_dict_for(name, meta, parts=("text_encoder", "decoder")):
-    cfg = config_for(name)
-    key = (name.split("_")[0], json.dumps(meta["sd_kw"], sort_keys=True), tuple(parts))
+    cfg = config_for(name, meta)
+    key = (name.split("_")[0], json.dumps(meta["sd_kw"], sort_keys=True), json.dumps(meta.get("cfg_kw"), sort_keys=True), tuple(parts))
     if key not in _sd_cache:
         _sd_cache.clear()  # mini dicts are GBs: keep one at a time
         _sd_cache[key] = synthetic_state_dict(cfg, parts=parts, **meta["sd_kw"])

@@ -169,3 +169,17 @@ __global__ void k(const bf16x8* a, const bf16x8* b, float* o) {
         src = os.path.join(td, "probe.hip")
         open(src, "w").write(probe)
         assert mod.main([src]) == 1
+
+
+def test_generation_config_refuses_fields_it_does_not_serve():
+    """A generation_config.json may carry fields this engine does not act on.  Bookkeeping keys and parameters at their
+    neutral defaults are ignored; anything that would change the reference's tokens is refused, not dropped."""
+    from parler_tts_amd.configuration import GenerationConfig
+
+    GenerationConfig(transformers_version="4.40.0", _from_model_config=True, repetition_penalty=1.0, no_repeat_ngram_size=0,
+                     min_new_tokens=10, output_attentions=False).validate()
+    assert GenerationConfig(min_new_tokens=10).min_new_tokens == 10
+    for bad in (dict(repetition_penalty=1.2), dict(no_repeat_ngram_size=3), dict(bad_words_ids=[[5]]), dict(typical_p=0.9),
+                dict(some_future_knob=1)):
+        with pytest.raises(NotImplementedError):
+            GenerationConfig(**bad).validate()

@@ -1,5 +1,6 @@
-"""world-size-2 gloo test of the data-parallel plumbing (CPU): the DP result must equal the single-process
-result row for row."""
+"""world-size-2 gloo tests of the data-parallel plumbing (CPU): the DP result must equal the single-process result row
+for row, with the call shape of the real API - ranks come back with DIFFERENT frame counts (a rank stops when its own rows
+have emitted EOS), a rank may own no row at all, and both gathers (codec ids, waveforms) carry per-row lengths."""
 import os
 import socket
 
@@ -10,16 +11,38 @@ import torch.multiprocessing as mp
 
 from parler_tts_amd.distributed import generate_data_parallel, shard_bounds
 
+PAD = 1024
 
-def fake_generate(input_ids, attention_mask=None, prompt_input_ids=None, prompt_attention_mask=None, frames=5, K=3):
-    """deterministic stand-in for model.generate(return_raw_ids=True)[0]: codes depend only on the row"""
+
+def fake_frames(input_ids):
+    """frames a slice 'generates': depends on its rows, so two ranks differ (like an EOS-dependent L_out)"""
+    return 3 + int(input_ids.sum()) % 5
+
+
+def fake_generate(input_ids, attention_mask=None, prompt_input_ids=None, prompt_attention_mask=None, K=3):
+    """deterministic stand-in for model.generate(return_raw_ids=True)[0]: [b, K, F] codes that depend only on the row,
+    F on the slice"""
     b = input_ids.shape[0]
+    frames = fake_frames(input_ids)
     base = input_ids.sum(dim=1, keepdim=True) + (0 if prompt_input_ids is None else prompt_input_ids.sum(dim=1, keepdim=True))
     if attention_mask is not None:
         base = base + attention_mask.sum(dim=1, keepdim=True)
     k = torch.arange(K).view(1, K, 1)
     f = torch.arange(frames).view(1, 1, frames)
     return (base.view(b, 1, 1) + 7 * k + 3 * f) % 1024
+
+
+def fake_waveform(input_ids, attention_mask=None, prompt_input_ids=None, prompt_attention_mask=None, hop=4):
+    codes = fake_generate(input_ids, attention_mask, prompt_input_ids, prompt_attention_mask)
+    return codes[:, 0, :].repeat_interleave(hop, dim=1).float() / 1024.0
+
+
+def _inputs(B):
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(2, 100, (B, 6), generator=g)
+    mask = (torch.rand(B, 6, generator=g) > 0.2).long()
+    prompt = torch.randint(2, 100, (B, 4), generator=g)
+    return ids, mask, prompt
 
 
 def _free_port():
@@ -34,37 +57,51 @@ def _worker(rank, world, port, B, out_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = torch.Generator().manual_seed(5)
-    ids = torch.randint(2, 100, (B, 6), generator=g)
-    mask = (torch.rand(B, 6, generator=g) > 0.2).long()
-    prompt = torch.randint(2, 100, (B, 4), generator=g)
+    ids, mask, prompt = _inputs(B)
     # only the source rank "has" the inputs
     args = dict(input_ids=ids, attention_mask=mask, prompt_input_ids=prompt) if rank == 0 else \
         dict(input_ids=None, attention_mask=None, prompt_input_ids=None)
-    codes = generate_data_parallel(fake_generate, **args, src=0, device="cpu", frames=5, K=3)
-    out_q.put((rank, codes.clone()))
+    codes, frames = generate_data_parallel(fake_generate, **args, src=0, device="cpu", gather="codes", pad_token_id=PAD, K=3)
+    wav, samples = generate_data_parallel(fake_waveform, **args, src=0, device="cpu", gather="waveform", hop=4)
+    out_q.put((rank, codes.clone(), frames.clone(), wav.clone(), samples.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("B", [5, 2, 1])
 def test_dp_equals_single_process(B):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=120) for _ in range(2))
+    got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    g = torch.Generator().manual_seed(5)
-    ids = torch.randint(2, 100, (B, 6), generator=g)
-    mask = (torch.rand(B, 6, generator=g) > 0.2).long()
-    prompt = torch.randint(2, 100, (B, 4), generator=g)
-    ref = fake_generate(ids, mask, prompt)
-    assert torch.equal(got[0], ref) and torch.equal(got[1], ref)
+    ids, mask, prompt = _inputs(B)
+    # what each slice produces on its own, padded by hand
+    parts, lens = [], []
+    for r in range(world):
+        lo, hi = shard_bounds(B, world, r)
+        if hi > lo:
+            c = fake_generate(ids[lo:hi], mask[lo:hi], prompt[lo:hi])
+            parts.append(c)
+            lens += [c.shape[-1]] * (hi - lo)
+    fmax = max(lens)
+    if B == 5:
+        assert len(set(lens)) > 1, "the test must exercise unequal lengths"
+    ref = torch.cat([torch.nn.functional.pad(c, (0, fmax - c.shape[-1]), value=PAD) for c in parts])
+    for r in range(world):
+        codes, frames, wav, samples = got[r]
+        assert codes.dtype == torch.long and torch.equal(codes, ref)
+        assert frames.tolist() == lens
+        assert samples.tolist() == [4 * n for n in lens] and wav.shape == (B, 4 * fmax)
+        for b in range(B):
+            assert torch.equal(wav[b, : samples[b]], (ref[b, 0, : lens[b]].repeat_interleave(4).float() / 1024.0))
+            assert (wav[b, samples[b]:] == 0).all() and (codes[b, :, frames[b]:] == PAD).all()
 
 
 def test_shard_bounds_cover_the_batch():

@@ -5,8 +5,14 @@ tests/test_oracle_vs_golden.py) and the committed golden fixtures are only the c
 Tolerances
   fp32 mode : token / code ids bit-exact on the fixtures (their top-2 logit margins are >= 6e-4, three
               orders above the fp32 re-association noise measured here); logits |diff| <= 2e-4
-  bf16 mode : weights + KV cache in bf16, fp32 accumulate: logits |diff| <= 0.08 (logit std is ~0.6),
-              teacher-forced argmax agreement >= 90 % of the kept positions
+  bf16 mode : weights + KV cache in bf16, fp32 accumulate.  Checked against oracle/cpu_ref_bf16.py, the CPU restatement
+              with bf16 roundings at the engine's rounding points.
+              Two bf16 pipelines with the same rounding points but another fp32 summation order drift apart (every
+              rounding turns an fp32-level difference into whole-ulp flips; cpu_ref_bf16.py header), the more the deeper
+              and wider the model.  The restatement is therefore evaluated twice, with fp32 and with fp64 accumulation, and
+              the engine must lie within max(BF16_TOL, 2x that re-association SPREAD) of it, the argmax equal wherever the
+              restatement's margin exceeds twice the bound.  Measured spreads: 4e-4 (tiny, 2 layers), ~5e-3 (mini_v0.1
+              widths cut to 2 layers), 1.3e-2 (mini_v0.1, 24 layers - where bf16 vs the fp32 reference is 1.7e-2 .. 8e-2).
 """
 import ctypes as C
 import os
@@ -18,6 +24,8 @@ import torch
 from tests.helpers import case_inputs, config_for, forced_tokens, free_positions, load_case, state_dict_for
 
 pytestmark = pytest.mark.gpu
+
+BF16_TOL = 4e-3      # one bf16 ulp of a value in [0.5, 1) is 2^-8 = 3.9e-3
 
 
 def _need_gpu():
@@ -41,7 +49,7 @@ def model_for(name, meta, dtype):
 
     cfg, sd = state_dict_for(name, meta, parts=("text_encoder", "decoder", "audio_encoder")
                              if name.startswith("tiny") else ("text_encoder", "decoder"))
-    key = (name.split("_")[0], str(meta["sd_kw"]), dtype)
+    key = (name.split("_")[0], str(meta["sd_kw"]), str(meta.get("cfg_kw")), dtype)
     if key not in _models:
         _models.clear()
         torch.cuda.empty_cache()
@@ -233,16 +241,58 @@ def test_fp32_tokens_bit_exact_and_logits_close(hip, name):
     assert np.array_equal(codes.numpy(), f["codes"])
 
 
-@pytest.mark.parametrize("name", ["tiny_greedy", "mini_greedy"])
-def test_bf16_teacher_forced_logits_and_agreement(hip, name):
+def _bf16_bound(cfg, spread):
+    """tolerance of a bf16 engine vs restatement comparison: one bf16 ulp of a logit in [0.5, 1), or 2x the restatement's own
+    re-association spread (its fp32-accumulate vs its fp64-accumulate evaluation) where that is larger"""
+    return max(BF16_TOL, 2.0 * float(spread))
+
+
+@pytest.mark.parametrize("name", ["tiny_greedy", "tiny_greedy_ragged", "tiny_cfg", "mini_greedy", "mini_greedy_ragged"])
+def test_bf16_teacher_forced_logits_against_the_bf16_restatement(hip, name):
+    """bf16 engine vs oracle/cpu_ref_bf16.py (same rounding points, CPU), every step of the fixture: logits within the bound
+    of _bf16_bound, argmax equal where the restatement's margin exceeds twice that; equal lengths, ragged masks, guidance."""
+    from oracle import cpu_ref_bf16
+
     f, cfg, raw, logits, pattern = run_engine_case(name, "bf16", teacher_force=True)
+    _, meta = load_case(name)
+    _, sd = state_dict_for(name, meta)
+    desc, amask, prompt, pmask = case_inputs(f)
+    kw = dict(forced=torch.from_numpy(f["raw_ids"]), record=int(f["max_length"]), guidance_scale=meta["gen"].get("guidance_scale"))
+    want = cpu_ref_bf16.generate_ids(cfg, sd, torch.from_numpy(f["enc_t5"]), amask, prompt, pmask, int(f["max_length"]), **kw)["step_logits"]
+    alt = cpu_ref_bf16.generate_ids(cfg, sd, torch.from_numpy(f["enc_t5"]), amask, prompt, pmask, int(f["max_length"]),
+                                    acc64=True, **kw)["step_logits"]
+    tol = _bf16_bound(cfg, (alt - want).abs().max())
+    n = min(want.shape[0], logits.shape[0])
+    diff = (logits[:n] - want[:n]).abs()
+    assert diff.max() < tol, (diff.max(), tol)
+    t2 = torch.topk(want[:n], 2, dim=-1)[0]
+    safe = (t2[..., 0] - t2[..., 1]) > 2 * tol
+    assert safe.float().mean() > 0.3
+    assert torch.equal(logits[:n].argmax(-1)[safe], want[:n].argmax(-1)[safe])
     gold = f["step_logits"]
-    n = min(gold.shape[0], logits.shape[0])
-    diff = np.abs(logits[:n].numpy() - gold[:n])
-    assert diff.max() < 0.08, diff.max()
-    free = free_positions(f["pattern"], n)
-    agree = (logits[:n].argmax(-1).numpy() == gold[:n].argmax(-1))[free]
-    assert agree.mean() >= 0.90, agree.mean()
+    m = min(n, gold.shape[0])
+    assert np.abs(logits[:m].numpy() - gold[:m]).max() < 0.08        # bf16 noise vs the fp32 reference
+
+
+def test_bf16_mini_widths_two_layers_against_the_restatement(hip):
+    """mini_v0.1 widths (D 1024, 16 heads, ffn 4096, 9 codebooks of 1088, batch 32: the GEMM, attention and selection
+    instances of the benchmark) cut to 2 layers, where two same-rounding bf16 pipelines have drifted least: every rounding
+    point of the engine is where the restatement has it - logits within the bound of _bf16_bound (here ~1e-2 on logits of
+    magnitude up to ~3, i.e. about one bf16 ulp), argmax equal outside twice that."""
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    cfg.decoder.num_hidden_layers = 2
+    sd = synthetic_state_dict(cfg, seed=7, never_eos=True, ln_jitter=0.1, parts=("decoder",))
+    for ragged in (False, True):
+        got, want, _, _ = _oracle_vs_engine(cfg, sd, "bf16", B=32, T=40, P=16, L=14, seed=8, steps=12, oracle="bf16", ragged=ragged)
+        tol = _bf16_bound(cfg, _oracle_vs_engine.spread)
+        assert tol < 1.5e-2 and (got - want).abs().max() < tol, (ragged, (got - want).abs().max(), tol)
+        t2 = torch.topk(want, 2, dim=-1)[0]
+        safe = (t2[..., 0] - t2[..., 1]) > 2 * tol
+        assert safe.float().mean() > 0.3
+        assert torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe])
 
 
 def test_paged_kv_is_layout_independent(hip):
@@ -263,6 +313,127 @@ def test_graph_replay_equals_eager_steps(hip):
     assert np.array_equal(codes[0].cpu().numpy(), f["codes"])
     free = free_positions(f["pattern"], int(f["max_length"]) - 1).T
     assert np.array_equal(model.last_raw_ids.cpu().numpy()[:, 1:][free], f["raw_ids"][:, 1:][free])
+
+
+# ------------------------------------------------------------------------------------------------
+# parity at depth: the reference's own long runs, teacher-forced on the device (ptts_set_forced_sequence)
+# ------------------------------------------------------------------------------------------------
+def run_forced_long(name, dtype, batch_pad=0):
+    """Engine teacher-forced along the fixture's raw ids under graph replay; returns the logits at the fixture's sampled
+    steps [n, rows, V], the engine's own choice of every step [steps, rows] and the fixture.  batch_pad > 0 appends that
+    many random utterances (free-running) so that the fixture rows run inside a larger batch."""
+    from parler_tts_amd import _hip
+    from parler_tts_amd.delay_pattern import build_delay_pattern_mask
+
+    f, meta = load_case(name)
+    cfg, model = model_for(name, meta, dtype)
+    desc, amask, prompt, pmask = case_inputs(f)
+    enc = torch.from_numpy(f["enc_t5"])
+    B0 = desc.shape[0]
+    if batch_pad:
+        g = torch.Generator().manual_seed(77)
+        enc = torch.cat([enc, torch.randn(batch_pad, *enc.shape[1:], generator=g) * enc.std()])
+        amask = torch.cat([amask, torch.ones(batch_pad, amask.shape[1], dtype=amask.dtype)])
+        prompt = torch.cat([prompt, torch.randint(2, cfg.vocab_size, (batch_pad, prompt.shape[1]), generator=g)])
+        if pmask is not None:
+            pmask = torch.cat([pmask, torch.ones(batch_pad, pmask.shape[1], dtype=pmask.dtype)])
+    K, B, L = cfg.decoder.num_codebooks, enc.shape[0], int(f["max_length"])
+    eng = model.engine(B, enc.shape[1], prompt.shape[1], L)
+    dev = "cuda:0"
+    ids = torch.full((B * K, 1), cfg.decoder.bos_token_id, dtype=torch.long)
+    ids, pattern = build_delay_pattern_mask(ids, cfg.decoder.bos_token_id, cfg.decoder.pad_token_id, L, K)
+    pattern = pattern.to(dev).contiguous()
+    raw = torch.full((B * K, L), cfg.decoder.pad_token_id, dtype=torch.long, device=dev)
+    raw[:, :1] = ids.to(dev)
+    forced = torch.full((B * K, L), -1, dtype=torch.long, device=dev)
+    forced[: B0 * K] = torch.from_numpy(f["raw_ids"]).to(dev)
+    own = torch.full((B * K, L), -1, dtype=torch.long, device=dev)
+    eng.set_forced_sequence(forced, own)
+    try:
+        eng.prefill(B, B, enc.to(dev).contiguous(), amask.to(dev, torch.int32).contiguous(), prompt.to(dev).contiguous(),
+                    None if pmask is None else pmask.to(dev, torch.int32).contiguous(), pattern, raw, 1)
+        sp = _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
+        logits, done = [], 0
+        for s_ in f["logit_steps"]:
+            n = int(s_) + 1 - done
+            eng.decode_steps(n, sp)
+            done += n
+            logits.append(eng.last_logits(B * K)[: B0 * K].cpu())
+        eng.decode_steps(L - 1 - done, sp)
+        torch.cuda.synchronize()
+        assert eng.state().cur_len == L
+    finally:
+        eng.set_forced_sequence(None)
+    assert torch.equal(raw[: B0 * K].cpu(), torch.from_numpy(f["raw_ids"]))          # the forcing took
+    return f, cfg, torch.stack(logits), own[: B0 * K, 1:].cpu().numpy().T
+
+
+@pytest.mark.parametrize("name", ["tinylong_greedy", "minilong_greedy"])
+def test_fp32_long_horizon_against_the_reference(hip, name):
+    """L = 2580 (tiny shape: 41 KV pages, positions > 2048) and L = 512 (mini_v0.1 shape) runs of the REAL reference.
+    fp32 engine, teacher-forced: logits of the sampled steps (first, page boundaries, S > 1024, S > 2048, the last 8)
+    within 2e-4, and the engine's own argmax equal to the reference's at EVERY step whose top-2 margin is >= 5e-4."""
+    f, cfg, logits, own = run_forced_long(name, "fp32")
+    d = np.abs(logits.numpy() - f["step_logits"])
+    assert d.max() < 2e-4, (d.max(), d.reshape(d.shape[0], -1).max(1))
+    L = int(f["max_length"])
+    free = free_positions(f["pattern"], L - 1)
+    ok = free & (f["margins"] >= 5e-4)
+    assert ok.mean() > 0.5 * free.mean()
+    assert np.array_equal(own[ok], f["raw_ids"][:, 1:].T[ok])
+    last = f["logit_steps"] >= L - 9
+    assert last.sum() >= 6 and d[last].max() < 2e-4
+
+
+def _bf16_long_reference(name, f):
+    """logits / own argmax / margins of the engine-numerics restatement along the fixture's raw ids"""
+    from oracle import cpu_ref_bf16
+
+    if name.startswith("mini"):                      # minutes of CPU: written by oracle/gen_golden.py --only-bf16
+        g, _ = load_case(name + "_bf16")
+        assert np.array_equal(g["logit_steps"], f["logit_steps"])
+        return g["step_logits"], g["own"], g["margins"], float(np.abs(g["step_logits"] - g["step_logits_acc64"]).max())
+    _, meta = load_case(name)
+    cfg, sd = state_dict_for(name, meta)
+    desc, amask, prompt, pmask = case_inputs(f)
+    dec = cpu_ref_bf16.EngineBf16Decoder(cfg, sd)
+    margins, orig = [], dec.logits
+
+    def wrapped(x):
+        lg = orig(x)
+        t2 = torch.topk(lg, 2, dim=-1)[0]
+        margins.append(t2[:, 0] - t2[:, 1])
+        return lg
+
+    dec.logits = wrapped
+    kw = dict(forced=torch.from_numpy(f["raw_ids"]), record=set(int(x) for x in f["logit_steps"]))
+    r = cpu_ref_bf16.generate_ids(cfg, sd, torch.from_numpy(f["enc_t5"]), amask, prompt, pmask, int(f["max_length"]), decoder=dec, **kw)
+    alt = cpu_ref_bf16.generate_ids(cfg, sd, torch.from_numpy(f["enc_t5"]), amask, prompt, pmask, int(f["max_length"]), acc64=True, **kw)
+    spread = float((alt["step_logits"] - r["step_logits"]).abs().max())
+    return r["step_logits"].numpy(), r["own"].numpy(), torch.stack(margins).numpy(), spread
+
+
+@pytest.mark.parametrize("name,pad", [("tinylong_greedy", 0), ("minilong_greedy", 0), ("minilong_greedy", 30)])
+def test_bf16_long_horizon_against_the_bf16_restatement(hip, name, pad):
+    """The benchmark precision (BASELINE configs[1]) held to the CPU restatement with the engine's rounding points, over the
+    same long runs: logits within the bound of _bf16_bound (one bf16 ulp on the 2-layer shape, 2x the restatement's own
+    re-association spread at 24 layers) at every sampled step incl. S > 2048, argmax equal wherever the restatement's margin
+    exceeds twice the bound.  pad = 30: the two fixture utterances run as rows 0-1 of a batch of 32 (the benchmark's m-tile
+    occupancy) and must give the same numbers."""
+    f, cfg, logits, own = run_forced_long(name, "bf16", batch_pad=pad)
+    want, want_own, margins, spread = _bf16_long_reference(name, f)
+    tol = _bf16_bound(cfg, spread)
+    d = np.abs(logits.numpy() - want)
+    assert d.max() < tol, (d.max(), tol, d.reshape(d.shape[0], -1).max(1))
+    L = int(f["max_length"])
+    free = free_positions(f["pattern"], L - 1)
+    ok = free & (margins >= 2 * tol)
+    assert ok.mean() > 0.3 * free.mean()
+    assert np.array_equal(own[ok], want_own[ok])
+    # bf16 noise proper, vs the fp32 reference (reported in the assertion message only if it is absurd)
+    noise = np.abs(logits.numpy() - f["step_logits"]).max()
+    assert noise < 0.2, noise
+
 
 
 # ------------------------------------------------------------------------------------------------
@@ -785,9 +956,12 @@ def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
 # ------------------------------------------------------------------------------------------------
 # shapes beyond the fixtures: more than one 32-row m-tile, and BASELINE configs[4] (scaled decoder)
 # ------------------------------------------------------------------------------------------------
-def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, check_t5=False):
+def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, check_t5=False, oracle="fp32", sampling=None):
     """teacher-forced along the ORACLE's greedy path; returns (engine logits, oracle logits, oracle ids).
-    ragged: right-padded descriptions and LEFT-padded prompts (training script T:916) with their masks."""
+    ragged: right-padded descriptions and LEFT-padded prompts (training script T:916) with their masks.
+    oracle = "bf16": the engine-numerics restatement (oracle/cpu_ref_bf16.py) instead of the fp32 one.
+    sampling = PttsSampling: the engine runs its sampling warpers (the draws are overridden by the teacher forcing) and the
+    returned "logits" are its post-warper probabilities."""
     from oracle import cpu_ref
     from parler_tts_amd import _hip
     from parler_tts_amd.delay_pattern import build_delay_pattern_mask
@@ -803,8 +977,21 @@ def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, che
         for b in range(1, B):
             amask[b, T - (7 * b) % (T // 2):] = 0
             pmask[b, : (5 * b) % (P // 2 + 1)] = 0
-    enc = cpu_ref.t5_encode(cfg, sd, desc, amask)
-    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, record_logits=steps)
+    if "text_encoder.shared.weight" in sd:
+        enc = cpu_ref.t5_encode(cfg, sd, desc, amask)
+    else:       # decoder-only state dict: random encoder states of the T5 width stand in for the text encoder
+        enc = torch.randn(B, T, cfg.text_encoder.d_model, generator=g)
+    if oracle == "bf16":
+        from oracle import cpu_ref_bf16
+
+        ref = cpu_ref_bf16.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, record=steps)
+        ref["step_logits"] = ref["step_logits"][:steps]
+        # the restatement's own re-association spread (see _bf16_bound)
+        alt = cpu_ref_bf16.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, record=steps, acc64=True,
+                                        forced=ref["raw_ids"])["step_logits"][:steps]
+        _oracle_vs_engine.spread = float((alt - ref["step_logits"]).abs().max())
+    else:
+        ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, record_logits=steps)
     _models.clear()
     torch.cuda.empty_cache()
     model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=dtype, device="cuda:0")
@@ -821,12 +1008,12 @@ def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, che
         assert ((enc_gpu - enc).abs() * amask[..., None]).max() < 2e-4
     eng.prefill(B, B, enc.to(dev).contiguous(), amask.to(dev, torch.int32).contiguous(), prompt.to(dev).contiguous(),
                 None if pmask is None else pmask.to(dev, torch.int32).contiguous(), pattern, raw, 1)
-    sp = _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
+    sp = sampling if sampling is not None else _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
     out = []
     for s in range(steps):
         eng.set_forced_tokens(ref["raw_ids"][:, s + 1])
         eng.decode_steps(1, sp)
-        out.append(eng.last_logits(B * K).cpu())
+        out.append(eng.last_logits(B * K, probs=sampling is not None).cpu())
     eng.set_forced_tokens(None)
     got_raw = raw[:, : steps + 1].cpu()
     del model
@@ -904,20 +1091,62 @@ def test_long_description_bf16_lookahead_off_path(hip):
     assert (got.argmax(-1)[safe] == want.argmax(-1)[safe]).float().mean() > 0.9
 
 
-def test_scaled_decoder_config_bf16(hip):
-    """BASELINE configs[4]: d_model 1536, 24 heads, ffn 6144, 24 layers (random init; bf16 engine only:
-    the fp32 parity mode keeps LayerNorm rows <= 1024 wide in LDS)"""
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_scaled_decoder_config_24_layers_batch8(hip, dtype):
+    """BASELINE configs[4] on its own workload: d_model 1536, 24 heads, ffn 6144, ALL 24 layers (random init), batch 8 = the
+    per-GPU share of batch 64 over 8 GPUs.  fp32 engine vs the fp32 oracle (LayerNorm rows of 1536 > 1024 take the folded
+    form, engine.hip ptts_create), bf16 engine vs the engine-numerics restatement; teacher-forced along the oracle's path."""
     from parler_tts_amd.configuration import scaled_config
     from parler_tts_amd.weights import synthetic_state_dict
 
     cfg = scaled_config()
-    cfg.decoder.num_hidden_layers = 6          # same widths, fewer layers: keeps the CPU oracle to seconds
-    sd = synthetic_state_dict(cfg, seed=5, never_eos=True, parts=("text_encoder", "decoder"))
-    got, want, _, _ = _oracle_vs_engine(cfg, sd, "bf16", B=3, T=8, P=4, L=12, seed=4, steps=8)
-    assert (got - want).abs().max() < 0.08
+    sd = synthetic_state_dict(cfg, seed=5, never_eos=True, parts=("decoder",))
+    got, want, ref_ids, got_raw = _oracle_vs_engine(cfg, sd, dtype, B=8, T=20, P=8, L=14, seed=4, steps=5, oracle=dtype)
+    tol = 3e-4 if dtype == "fp32" else _bf16_bound(cfg, _oracle_vs_engine.spread)
+    assert (got - want).abs().max() < tol, ((got - want).abs().max(), tol)
     top2 = torch.topk(want, 2, dim=-1)[0]
-    safe = (top2[..., 0] - top2[..., 1]) > 0.05
-    assert (got.argmax(-1)[safe] == want.argmax(-1)[safe]).float().mean() > 0.97
+    safe = (top2[..., 0] - top2[..., 1]) > 2 * tol
+    assert safe.float().mean() > 0.3
+    assert torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_sampling_mini_batch32_topk50_temperature07(hip, dtype):
+    """BASELINE configs[3] on its own workload: parler_tts_mini_v0.1 shapes, batch 32, T = 40, P = 16, do_sample with
+    top_k = 50 and temperature = 0.7.  Post-warper probability vectors of the first decode steps (teacher-forced along the
+    oracle's path) within 1e-5 (fp32 engine vs the fp32 oracle); bf16 engine vs the engine-numerics restatement in log space
+    within what its logit bound allows; identical survivor sets where the k-th largest score is not a near-tie; Philox
+    determinism."""
+    from oracle import cpu_ref
+    from parler_tts_amd import _hip
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    sd = synthetic_state_dict(cfg, seed=1234, never_eos=True, parts=("decoder",))
+    sp = _hip.PttsSampling(1, 0.7, 50, 1.0, 99)
+    steps = 3
+    got, want, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=32, T=40, P=16, L=12, seed=1234, steps=steps, oracle=dtype, sampling=sp)
+    ref = torch.softmax(cpu_ref.warp_logits(want, 0.7, 50), dim=-1)
+    ltol = 3e-4 if dtype == "fp32" else _bf16_bound(cfg, _oracle_vs_engine.spread)
+    # a logit difference d moves a probability p by at most ~ p * 2d / temperature: 1e-5 (fp32) / SURVEY 8d's 1e-3 (bf16)
+    if dtype == "fp32":
+        assert (got - ref).abs().max() < 1e-5, (got - ref).abs().max()
+    else:
+        # a logit moved by at most ltol moves log p by at most 2 * ltol / temperature (its own score and the normaliser);
+        # SURVEY 8d's flat 1e-3 does not hold at 24 layers, where two same-rounding bf16 pipelines already differ by ~1e-2
+        both = (got > 0) & (ref > 0)
+        dlog = (got[both].log() - ref[both].log()).abs().max()
+        assert dlog < 2 * ltol / 0.7 + 1e-4, (dlog, ltol)
+        assert (got - ref).abs().max() < 2 * ltol / 0.7 * float(ref.max()) + 1e-4
+    assert ((got > 0).sum(-1) >= 50).all() and torch.allclose(got.sum(-1), torch.ones(got.shape[:-1]), atol=1e-5)
+    # survivor sets: equal for every row whose 50th / 51st largest scores are further apart than the logit tolerance
+    srt = torch.sort(want, dim=-1, descending=True)[0]
+    clear = (srt[..., 49] - srt[..., 50]) > (1e-3 if dtype == "fp32" else 2 * ltol)
+    assert clear.float().mean() > 0.5
+    assert torch.equal((got > 0)[clear], (ref > 0)[clear])
+    got2, _, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=32, T=40, P=16, L=12, seed=1234, steps=steps, oracle=dtype, sampling=sp)
+    assert torch.equal(got, got2)
 
 
 def test_top_p_warper_matches_oracle(hip):
@@ -1304,3 +1533,113 @@ def test_lookahead_cross_q_two_m_tiles_bf16(hip):
     assert not torch.isnan(a).any()
     assert (a - b).abs().max().item() < 0.05
     assert (a.argmax(-1) == b.argmax(-1)).float().mean().item() > 0.97
+
+
+# ------------------------------------------------------------------------------------------------
+# generation-config semantics added in round 2
+# ------------------------------------------------------------------------------------------------
+def test_num_return_sequences_reproduces_the_reference_expansion(hip):
+    """M:2600-2606: `_expand_inputs_for_generation` interleaves the id rows, the kwargs and the stashed delay pattern.  The
+    engine is teacher-forced (device-side) along the REFERENCE's sampled ids of the fixture, so generate() must return the
+    reference's [B, K, n * F] codes and its raw ids, and the warped probabilities of the last step must match."""
+    from oracle import cpu_ref
+
+    f, meta = load_case("tiny_sample_nrs2")
+    cfg, model = model_for("tiny_sample_nrs2", meta, "fp32")
+    desc, amask, prompt, _ = case_inputs(f)
+    L, K, n = int(f["max_length"]), cfg.decoder.num_codebooks, 2
+    B = desc.shape[0]
+    eng = model.engine(B * n, desc.shape[1], prompt.shape[1], L)
+    forced = torch.from_numpy(f["raw_ids"]).to("cuda:0")
+    assert forced.shape == (B * K * n, L)
+    eng.set_forced_sequence(forced)
+    try:
+        codes = model.generate(encoder_outputs=(torch.from_numpy(f["enc_t5"]),), attention_mask=amask, prompt_input_ids=prompt,
+                               do_sample=True, temperature=0.7, top_k=50, num_return_sequences=n, max_length=L, seed=5,
+                               return_raw_ids=True)
+        assert model.engine(B * n, desc.shape[1], prompt.shape[1], L) is eng
+        probs = eng.last_logits(B * K * n, probs=True).cpu()
+    finally:
+        eng.set_forced_sequence(None)
+    assert torch.equal(model.last_raw_ids.cpu(), torch.from_numpy(f["raw_ids"]))
+    assert codes.shape == (1, B, K, n * (L - K)) and np.array_equal(codes[0].cpu().numpy(), f["codes"])
+    ref = torch.softmax(cpu_ref.warp_logits(torch.from_numpy(f["step_logits"][-1]), 0.7, 50), dim=-1)
+    assert (probs - ref).abs().max() < 1e-5
+    with pytest.raises(ValueError):        # greedy keeps the reference's refusal (M:2575-2579)
+        model.generate(input_ids=desc, prompt_input_ids=prompt, do_sample=False, num_return_sequences=2, max_length=L)
+
+
+def test_min_length_and_min_new_tokens_suppress_eos(hip):
+    """MinLength / MinNewTokensLength processors of the third-party `_get_logits_processor` (called at M:2561-2567):
+    score[eos] = -inf while the id matrix is shorter than the bound.  A tiny model whose codebook-0 head prefers EOS from
+    step 6 on (its EOS row is the row of the token the free run picks there, times 1.05): without a bound utterance 0 ends
+    early; with one the engine must follow the oracle run that carries the same processor."""
+    from oracle import cpu_ref
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+
+    f, meta = load_case("tiny_eos_free")
+    cfg, sd0 = state_dict_for("tiny_eos_free", meta)
+    desc, amask, prompt, _ = case_inputs(f)
+    L, eos, K = int(f["max_length"]), cfg.decoder.eos_token_id, cfg.decoder.num_codebooks
+    enc = torch.from_numpy(f["enc_t5"])
+    col = 7                                               # a free column of codebook 0 (its BOS run ends at column 0)
+    tok = int(f["raw_ids"][0, col])
+    sd = dict(sd0)
+    h0 = sd["decoder.lm_heads.0.weight"].clone()
+    h0[eos] = h0[tok] * 1.05
+    sd["decoder.lm_heads.0.weight"] = h0
+    plain = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, None, L)["raw_ids"]
+    assert bool((plain[0, 1:col + 1] == eos).any())      # the modified head does emit EOS early
+    bound = col + 6
+
+    def min_len_proc(ids, scores):
+        if ids.shape[-1] < bound:
+            scores = scores.clone()
+            scores[:, eos] = -float("inf")
+        return scores
+
+    want = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, None, L, logits_processor=[min_len_proc])["raw_ids"]
+    assert not bool((want[:, 1:bound] == eos).any()) and not torch.equal(want, plain)
+    _models.clear()
+    torch.cuda.empty_cache()
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device="cuda:0")
+    kw0 = dict(encoder_outputs=(enc,), attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L, return_raw_ids=True)
+    model.generate(**kw0)
+    assert torch.equal(model.last_raw_ids.cpu(), plain)
+    for kw in (dict(min_length=bound), dict(min_new_tokens=bound - 1)):                 # start_len = 1
+        model.generate(**kw0, **kw)
+        got = model.last_raw_ids.cpu()
+        assert got.shape == want.shape and torch.equal(got, want), kw
+    with pytest.raises(NotImplementedError):       # the reference's processor order makes the guidance combine NaN there
+        model.generate(**{**kw0, "guidance_scale": 3.0, "min_length": bound})
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_unseeded_sampling_consumes_the_global_generator(hip):
+    """do_sample without `seed`: like torch.multinomial in the reference, every call draws from torch's global CPU generator,
+    so two calls differ and torch.manual_seed reproduces; an explicit seed stays deterministic."""
+    f, meta = load_case("tiny_sample")
+    cfg, model = model_for("tiny_sample", meta, "fp32")
+    desc, amask, prompt, _ = case_inputs(f)
+    kw = dict(encoder_outputs=(torch.from_numpy(f["enc_t5"]),), attention_mask=amask, prompt_input_ids=prompt, do_sample=True,
+              top_k=50, temperature=1.0, max_length=int(f["max_length"]), return_raw_ids=True)
+    torch.manual_seed(1234)
+    a = model.generate(**kw).clone()
+    b = model.generate(**kw).clone()
+    assert not torch.equal(a, b)
+    torch.manual_seed(1234)
+    assert torch.equal(model.generate(**kw), a)
+    assert torch.equal(model.generate(seed=3, **kw), model.generate(seed=3, **kw))
+
+
+def test_model_on_its_own_device_while_another_is_current(hip):
+    """generate() and the codec wrappers select the model's device themselves (streams, lazy workspaces and launches follow
+    the CURRENT device): with one GPU this checks that the guard is in place and harmless."""
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, "fp32")
+    desc, amask, prompt, _ = case_inputs(f)
+    codes = model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False,
+                           max_length=int(f["max_length"]), return_raw_ids=True)
+    assert np.array_equal(codes[0].cpu().numpy(), f["codes"])
+    assert torch.cuda.current_device() == 0
