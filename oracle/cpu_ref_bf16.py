@@ -146,11 +146,11 @@ class EngineBf16Decoder:
         for w in self.layers:
             kv = lin(hb, w["ckv"])                                                 # [B, T, 2D]
             k, v = kv[..., : self.D], kv[..., self.D:]
-            self.ck.append(rnd(k).view(B, T, self.H, self.hd).transpose(1, 2).contiguous())
-            self.cv.append(rnd(v).view(B, T, self.H, self.hd).transpose(1, 2).contiguous())
+            self.ck.append(rnd(k).view(B, T, self.H, self.hd).transpose(1, 2).contiguous().to(self.wdt))
+            self.cv.append(rnd(v).view(B, T, self.H, self.hd).transpose(1, 2).contiguous().to(self.wdt))
         self.cross_bias = torch.where(attention_mask.bool(), 0.0, FMIN)[:, None, None, :].float()      # M:875-879
-        self.sk = [torch.zeros(B, self.H, max_positions, self.hd) for _ in self.layers]
-        self.sv = [torch.zeros(B, self.H, max_positions, self.hd) for _ in self.layers]
+        self.sk = [torch.zeros(B, self.H, max_positions, self.hd, dtype=self.wdt) for _ in self.layers]     # bf16 VALUES,
+        self.sv = [torch.zeros(B, self.H, max_positions, self.hd, dtype=self.wdt) for _ in self.layers]     # held in wdt
         self.self_bias = torch.zeros(B, max_positions)
         self.n = 0                                                                 # cached self positions
 
@@ -162,11 +162,11 @@ class EngineBf16Decoder:
     def _attend(self, q, k, v, bias):
         """q [B,H,1,hd] fp32 (scaled), k / v [B,H,S,hd] (bf16 values); attn.hip: scores + bias, exact fp32 softmax, P.V"""
         wdt = self.wdt
-        s = torch.matmul(q.to(wdt), k.to(wdt).transpose(2, 3)).float()
+        s = torch.matmul(q.to(wdt), k.transpose(2, 3)).float()
         if bias is not None:
             s = s + bias
         p = F.softmax(s, dim=-1)
-        return torch.matmul(p.to(wdt), v.to(wdt)).float().transpose(1, 2).reshape(q.shape[0], self.D)
+        return torch.matmul(p.to(wdt), v).float().transpose(1, 2).reshape(q.shape[0], self.D)
 
     def _ln(self, x, gb):
         return F.layer_norm(x, (self.D,), gb[0], gb[1])
@@ -181,8 +181,8 @@ class EngineBf16Decoder:
             x0b = rnd(x)
             y = lin(self._ln(x, w["ln1"]), w["qkv"]) if self.exact else w["qkv_f"](x0b)
             q = (y[:, :D] * scale).view(B, 1, H, hd).transpose(1, 2)
-            self.sk[l][:, :, n] = rnd(y[:, D:2 * D]).view(B, H, hd)
-            self.sv[l][:, :, n] = rnd(y[:, 2 * D:]).view(B, H, hd)
+            self.sk[l][:, :, n] = rnd(y[:, D:2 * D]).view(B, H, hd).to(self.wdt)
+            self.sv[l][:, :, n] = rnd(y[:, 2 * D:]).view(B, H, hd).to(self.wdt)
             a = rnd(self._attend(q, self.sk[l][:, :, : n + 1], self.sv[l][:, :, : n + 1], sb))
             x1 = x + lin(a, w["o"])
             if self.exact:
@@ -223,6 +223,20 @@ class EngineBf16Decoder:
         return row + self.pos[self.n]
 
 
+_decoders: Dict = {}
+
+
+def decoder_for(cfg, sd, exact=False, lookahead=None, acc64=False) -> EngineBf16Decoder:
+    """folded / rounded weight sets are expensive to build (24 layers at mini_v0.1 widths: ~10 s): keep the last few, keyed
+    by the identity of the state dict"""
+    key = (id(sd), exact, lookahead, acc64)
+    if key not in _decoders:
+        while len(_decoders) >= 2:
+            _decoders.pop(next(iter(_decoders)))
+        _decoders[key] = (sd, EngineBf16Decoder(cfg, sd, exact=exact, lookahead=lookahead, acc64=acc64))
+    return _decoders[key][1]
+
+
 @torch.no_grad()
 def generate_ids(cfg: ParlerTTSConfig, sd, encoder_states, attention_mask, prompt_input_ids, prompt_attention_mask,
                  max_length: int, exact: bool = False, forced: Optional[torch.Tensor] = None, record=None,
@@ -244,7 +258,7 @@ def generate_ids(cfg: ParlerTTSConfig, sd, encoder_states, attention_mask, promp
         pids = None if pids is None else pids.repeat(2, 1)
         pmask = None if pmask is None else pmask.repeat(2, 1)
     P = 0 if pids is None else pids.shape[1]
-    m = decoder or EngineBf16Decoder(cfg, sd, exact=exact, lookahead=lookahead, acc64=acc64)
+    m = decoder or decoder_for(cfg, sd, exact=exact, lookahead=lookahead, acc64=acc64)
     m.start(enc, amask, P + max_length)
     if pmask is not None:
         m.mask_positions(0, pmask)

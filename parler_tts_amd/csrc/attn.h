@@ -28,6 +28,11 @@ struct AttnArgs {
     // folded QKV projection; the kernel finishes the LayerNorm of its head's three 64-wide slices (c1 / c2 are [3 D]), scales
     // q, and appends the k / v rows to the cache at state->pos itself before it streams the cache
     int lnfix_qkv = 0;       // 1: always use the general kernel (A/B and equivalence tests)
+    // batched prefill: query row r belongs to utterance r / rows_per_utt (its KV pages, its mask row); decode: 1
+    int rows_per_utt = 1;
+    // causal prefill kernel only: the launch covers positions pos0 .. pos0 + npos - 1 of every utterance; query row
+    // b * npos + i sits at cache position pos0 + i and attends the keys 0 .. pos0 + i (M:870-872 causal mask)
+    int npos = 0, pos0 = 0;
 };
 
 struct FullAttnArgs {
@@ -46,4 +51,6 @@ hipError_t attn_init();
 // kernel's own begin -> end (what a profiler reports), without barrier packets around it
 hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream,
                               hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// causal self-attention of a prefill chunk (a.npos positions per utterance, B utterances): one wave per query row
+hipError_t attn_causal_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream);
 hipError_t attn_full_launch(const FullAttnArgs& a, int B, int out_dtype, hipStream_t stream);

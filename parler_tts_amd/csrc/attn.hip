@@ -67,16 +67,17 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     float* wred = red + NWAVES * 64;                              // [NWAVES] cross-wave scalars
     int* pages = reinterpret_cast<int*>(wred + NWAVES);           // [max_blocks] this utterance's page ids
 
-    const int h = blockIdx.x, b = blockIdx.y;
+    const int h = blockIdx.x, b = blockIdx.y;                    // b: query row; bu: the utterance whose cache it reads
+    const int bu = b / a.rows_per_utt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int S = a.len_from_state ? (a.state->pos + 1) : a.len;
     const int tt = lane / LPT, c = lane % LPT;                    // token-in-tile, 16-byte chunk of the row
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
 
     float q[EPL];
-    const float* bias = a.bias ? a.bias + (size_t)b * a.ld_bias : nullptr;
+    const float* bias = a.bias ? a.bias + (size_t)bu * a.ld_bias : nullptr;
     // page ids once into LDS: KV addresses then depend on no global load
-    for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[b * a.pool.max_blocks + i];
+    for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[bu * a.pool.max_blocks + i];
     const size_t page_elems = a.pool.page_elems();       // stride between two pages inside this head's K (or V) slab
     const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
@@ -259,10 +260,11 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
+    const int bu = b / a.rows_per_utt;          // query row b reads utterance bu's page and mask row
     const int S = a.len;
     const int tt = lane / LPT, c = lane % LPT;
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
-    const int page = a.pool.block_table[b * a.pool.max_blocks];
+    const int page = a.pool.block_table[bu * a.pool.max_blocks];
     const elem_t* kp = pool + (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() +
                        (size_t)page * a.pool.page_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     raw_t kb[NT], vb[NT];
     float bs[NT];
     const bool has_bias = a.bias != nullptr;
-    const float* brow = has_bias ? a.bias + (size_t)b * a.ld_bias : a.q;   // a.q: any readable floats, result unused
+    const float* brow = has_bias ? a.bias + (size_t)bu * a.ld_bias : a.q;   // a.q: any readable floats, result unused
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         int tok = u * TPW + tt;
@@ -382,6 +384,98 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Causal self-attention of a batched prefill chunk (reference M:264-382 with tgt_len = npos under the 4-D causal mask
+// of M:870-872): the chunk's K / V rows are already in the paged cache (QKV projection epilogue), so query row
+// (utterance b, position pos0 + i) is a single-query attention over the keys 0 .. pos0 + i - the decode kernel's
+// arithmetic with ONE WAVE per query instead of one workgroup: tiles of TPW keys, scores to the wave's LDS row, exact
+// fp32 softmax (max, exp, sum, divide), P.V, output in fragment order.  A one-off phase: P + prefix positions.
+// ------------------------------------------------------------------------------------------------
+template <typename P, typename OP>
+__global__ __launch_bounds__(NWAVES * 64) void attn_causal_kernel(AttnArgs a, int s_max) {
+    typedef typename P::elem_t elem_t;
+    typedef KVLoad<P> L;
+    typedef typename L::raw_t raw_t;
+    constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = blockIdx.z * NWAVES + w;                       // position inside the chunk (uniform per wave)
+    float* sc = reinterpret_cast<float*>(smem) + (size_t)w * s_max;
+    if (i >= a.npos) return;                                     // whole wave; no workgroup barrier below
+    const int S = a.pos0 + i + 1;
+    const int row = b * a.npos + i;
+    const int tt = lane / LPT, c = lane % LPT;
+    const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
+    const int* table = a.pool.block_table + (size_t)b * a.pool.max_blocks;
+    const size_t page_elems = a.pool.page_elems();
+    const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
+    const size_t v_off = a.pool.kv_elems();
+    const float* bias = a.bias ? a.bias + (size_t)b * a.ld_bias : nullptr;
+    float q[EPL];
+    {
+        const float* qp = a.q + (size_t)row * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) q[j] = qp[j];
+    }
+    const int ntiles = (S + TPW - 1) / TPW;
+    auto kv_ptr = [&](int tok, size_t add) {
+        return reinterpret_cast<const raw_t*>(pool + (size_t)table[tok >> 6] * page_elems + head_off + add +
+                                              (size_t)(tok & 63) * PTTS_HEAD_DIM);
+    };
+    float m = -INFINITY;
+    for (int t = 0; t < ntiles; ++t) {
+        int tok = t * TPW + tt;
+        const bool live = tok < S;
+        if (!live) tok = S - 1;
+        float kf[EPL];
+        L::unpack(*kv_ptr(tok, 0), kf);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) d = fmaf(q[j], kf[j], d);
+        d = (LPT == 8) ? sum_oct(d) : sum_row16(d);
+        if (bias) d += bias[tok];
+        if (c == 0 && live) sc[tok] = d;
+        if (live) m = fmaxf(m, d);
+    }
+    m = wave_max(m);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float sum = 0.f;
+    for (int t = lane; t < S; t += 64) {
+        const float e = expf(sc[t] - m);
+        sc[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float acc[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+        int tok = t * TPW + tt;
+        const bool live = tok < S;
+        if (!live) tok = S - 1;
+        const float p = live ? sc[tok] / sum : 0.f;
+        float vf[EPL];
+        L::unpack(*kv_ptr(tok, v_off), vf);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        if (LPT == 8) acc[j] += dpp_f<0x128>(acc[j]);
+        acc[j] += __shfl_xor(acc[j], 16);
+        acc[j] += __shfl_xor(acc[j], 32);
+    }
+    if (tt == 0) {
+        typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(row >> 5) * 32 * a.D;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) of[frag_off<OP>(row & 31, h * PTTS_HEAD_DIM + c * EPL + j)] = to_elem<OP>(acc[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Full (bidirectional) attention for the T5 encoder: T <= 512 tokens, one workgroup per (head, b).
 // scores = q.k (no scaling) + rel-pos bias[h][bucket(j - i)] + (1 - mask_j) * finfo.min; softmax fp32.
 // (HF:models/t5/modeling_t5.py:144-173, 217-280.)  q/k/v row-major fp32 [B*T][3*inner] as written by
@@ -445,6 +539,14 @@ hipError_t attn_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PBF16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    const void* causal[4] = {reinterpret_cast<const void*>(attn_causal_kernel<PBF16, PBF16>),
+                             reinterpret_cast<const void*>(attn_causal_kernel<PBF16, PF32>),
+                             reinterpret_cast<const void*>(attn_causal_kernel<PF32, PBF16>),
+                             reinterpret_cast<const void*>(attn_causal_kernel<PF32, PF32>)};
+    for (const void* k : causal) {
+        e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PF32>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -482,6 +584,22 @@ hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, 
         else PTTS_ATTN_LAUNCH(PF32, PF32);
     }
 #undef PTTS_ATTN_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t attn_causal_launch(const AttnArgs& a, int B, int H, int cache_dtype, int out_dtype, hipStream_t stream) {
+    if (a.npos <= 0) return hipErrorInvalidValue;
+    const int s_max = (a.pos0 + a.npos + 3) & ~3;
+    const size_t lds = (size_t)NWAVES * s_max * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid(H, B, (a.npos + NWAVES - 1) / NWAVES), block(NWAVES * 64);
+    if (cache_dtype == PTTS_BF16) {
+        if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_causal_kernel<PBF16, PBF16>), grid, block, lds, stream, a, s_max);
+        else hipLaunchKernelGGL((attn_causal_kernel<PBF16, PF32>), grid, block, lds, stream, a, s_max);
+    } else {
+        if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_causal_kernel<PF32, PBF16>), grid, block, lds, stream, a, s_max);
+        else hipLaunchKernelGGL((attn_causal_kernel<PF32, PF32>), grid, block, lds, stream, a, s_max);
+    }
     return hipGetLastError();
 }
 

@@ -85,6 +85,14 @@ struct EventPair {
     int kind;  // 0 = self-attention launch, 1 = whole step
 };
 
+// Activation workspaces of one pass through the decoder layers.  The decode step owns a set sized for max_batch rows;
+// the batched prefill owns a larger one (rows = utterances x positions of a chunk), allocated on first use.
+struct Work {
+    float *x = nullptr, *q = nullptr, *xstat = nullptr;
+    void *attn_frag = nullptr, *mlp_frag = nullptr, *x_frag = nullptr, *x_frag2 = nullptr;
+    int rows = 0;      // capacity (multiple of 32)
+};
+
 }  // namespace
 
 struct ptts_engine {
@@ -110,6 +118,9 @@ struct ptts_engine {
     void* x_frag2 = nullptr;   // second fragment buffer (the out-projection reads the old rows while writing the new)
     void* xf_cur = nullptr;    // fragment buffer that holds the current residual rows
     float* xstat = nullptr;    // per-block row statistics of the rows the out-projection wrote
+    Work pf;                   // batched-prefill workspaces (lazy)
+    bool seq_prefill = false;  // PTTS_PREFILL_SEQ=1: the round-1 prefill, one cached position at a time (A/B, tests)
+    int pf_chunk = 128;        // positions per batched-prefill chunk (PTTS_PREFILL_CHUNK)
     bool no_page_kernel = false;   // PTTS_ATTN_NO_PAGE_KERNEL=1: cross-attention on the general kernel (A/B, tests)
     float *lnf_g = nullptr, *lnf_b = nullptr, *enc_proj_bias = nullptr;
     void *embed_tokens = nullptr, *pos_table = nullptr, *embed_prompts = nullptr;
@@ -314,10 +325,22 @@ int refresh_folds(ptts_engine* e, hipStream_t s) {
     return PTTS_OK;
 }
 
-// ---- one decoder layer stack over B_eff rows at the current position (decode token or prompt token) ----
-int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
+Work decode_work(ptts_engine* e) {
+    Work w;
+    w.x = e->x; w.q = e->q; w.xstat = e->xstat; w.attn_frag = e->attn_frag; w.mlp_frag = e->mlp_frag;
+    w.x_frag = e->x_frag; w.x_frag2 = e->x_frag2; w.rows = e->mtiles * 32;
+    return w;
+}
+
+// ---- one pass through the decoder layer stack ----
+// decode (npos = 0): M = B_eff rows, one per utterance, at the position StepState.pos holds.
+// batched prefill (npos > 0): M = B_eff * npos rows, row b * npos + i = cache position pos0 + i of utterance b; the QKV
+// epilogue appends every row's k / v at its own position, self-attention is causal over the cache (attn_causal_kernel),
+// cross-attention rows read their utterance's description keys.  Same GEMM kernels (m-tiles in gridDim.y).
+int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int M, int npos = 0, int pos0 = 0) {
     const ptts_config& c = e->cfg;
-    const int D = c.hidden, F = c.ffn, M = e->B_eff;
+    const int D = c.hidden, F = c.ffn;
+    const int B_utt = npos > 0 ? M / npos : M;
     const float scale = 1.0f / sqrtf((float)PTTS_HEAD_DIM);
     for (int l = 0; l < c.layers; ++l) {
         DecLayer& w = e->layers[l];
@@ -325,24 +348,24 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
         // LN1 + fused QKV projection; q scaled (M:282), k/v appended to the paged cache (M:299-304)
         // Look-ahead QKV (layers behind the first): the raw product x.Wqkv'^T was computed by the previous layer's fc2 launch
         // (second role, below); the self-attention kernel finishes the LayerNorm, scales q and appends k / v itself.
-        const bool pre_qkv = e->look2_active && l > 0;
+        const bool pre_qkv = e->look2_active && l > 0 && npos == 0;
         if (!pre_qkv) {
             g = GemmArgs();
             g.W = w.qkv.ptr; g.N = 3 * D; g.K = D; g.M = M;
-            g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.eps = 1e-5f;
+            g.pro = PRO_LAYERNORM; g.x = wk.x; g.ldx = D; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.eps = 1e-5f;
             use_fold(e, &g, w.qkv_f, 0);
-            g.epi = EPI_QKV_SELF; g.out = e->q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
-            g.state = e->state; g.D = D;
+            g.epi = EPI_QKV_SELF; g.out = wk.q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
+            g.state = e->state; g.D = D; g.npos = npos; g.pos0 = pos0;
             DBG_GATE(e);
             PTTS_TRY(launch_gemm(e, g, s));
         }
-        // self attention over pos+1 cached tokens
+        // self attention over the cached tokens
         AttnArgs a;
-        a.q = e->q; a.ldq = D; a.pool = make_pool(e, false); a.layer = l; a.len_from_state = 1; a.state = e->state;
+        a.q = wk.q; a.ldq = D; a.pool = make_pool(e, false); a.layer = l; a.len_from_state = 1; a.state = e->state;
         a.bias = e->has_self_bias ? e->self_bias : nullptr; a.ld_bias = e->s_cap; a.s_cap = e->s_cap;
-        a.ofrag = e->attn_frag; a.D = D;
+        a.ofrag = wk.attn_frag; a.D = D;
         if (pre_qkv) {
-            a.q = e->qkv_raw; a.ldq = 3 * D; a.lnfix_qkv = 1; a.lnfix_stat = e->xstat; a.lnfix_blocks = D / 16;
+            a.q = e->qkv_raw; a.ldq = 3 * D; a.lnfix_qkv = 1; a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16;
             a.lnfix_c1 = w.qkv_f.c1; a.lnfix_c2 = w.qkv_f.c2; a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
         }
         EventPair* ep = nullptr;
@@ -352,21 +375,26 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
             ep->bytes = 2.0 * M * (double)(e->host_pos + 1) * D * (double)e->esz;
         }
         DBG_GATE(e);
-        // sampled launches carry their own start / stop events (hipExtLaunchKernel): the dispatch's timestamps
-        HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr));
+        if (npos > 0) {
+            a.npos = npos; a.pos0 = pos0;
+            HIP_TRY(attn_causal_launch(a, B_utt, c.heads, e->dt, e->dt, s));
+        } else {
+            // sampled launches carry their own start / stop events (hipExtLaunchKernel): the dispatch's timestamps
+            HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr));
+        }
         // out_proj + residual (M:380, M:460)
         const bool look = e->look_active;
         g = GemmArgs();
-        g.W = w.o.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
+        g.W = w.o.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.attn_frag;
+        g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
         if (look) {
             // look-ahead cross-q: LN2(x + a.Wo^T).Wq^T = rstd * ((x.Wq'^T + a.(Wq'.Wo)^T) - mean * c1) + c2, so the
             // raw product needs only the rows this launch STARTS from and its own input: extra workgroups of the same
             // launch compute it into `q`; the updated rows go to the other fragment buffer, their per-block statistics
             // to `xstat`, and the cross-attention kernel applies the LayerNorm when it loads q.
-            void* next = e->xf_cur == e->x_frag ? e->x_frag2 : e->x_frag;
+            void* next = e->xf_cur == wk.x_frag ? wk.x_frag2 : wk.x_frag;
             g.W2 = w.look; g.N2 = D; g.K2 = 2 * D; g.xfrag_lo = e->xf_cur; g.ksplit = D / (e->dt == PTTS_DTYPE_BF16 ? 32 : 16);
-            g.out2 = e->q; g.ldo2 = D; g.xfrag_out = next; g.xstat = e->xstat;
+            g.out2 = wk.q; g.ldo2 = D; g.xfrag_out = next; g.xstat = wk.xstat;
             e->xf_cur = next;
         }
         DBG_GATE(e);
@@ -375,47 +403,48 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile) {
             // LN2 + cross-attention query (M:467-471)
             g = GemmArgs();
             g.W = w.cq.ptr; g.N = D; g.K = D; g.M = M;
-            g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.eps = 1e-5f;
+            g.pro = PRO_LAYERNORM; g.x = wk.x; g.ldx = D; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.eps = 1e-5f;
             use_fold(e, &g, w.cq_f, 1);
-            g.epi = EPI_Q_SCALE; g.out = e->q; g.ldo = D; g.scale = scale;
+            g.epi = EPI_Q_SCALE; g.out = wk.q; g.ldo = D; g.scale = scale;
             DBG_GATE(e);
             PTTS_TRY(launch_gemm(e, g, s));
         }
         // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294)
         a = AttnArgs();
-        a.q = e->q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
+        a.q = wk.q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
         a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS;
-        a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = e->attn_frag; a.D = D;
+        a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = wk.attn_frag; a.D = D;
         a.no_page_kernel = e->no_page_kernel ? 1 : 0;
+        a.rows_per_utt = npos > 0 ? npos : 1;
         if (look) {
-            a.lnfix_stat = e->xstat; a.lnfix_blocks = D / 16; a.lnfix_c1 = w.cq_f.c1; a.lnfix_c2 = w.cq_f.c2;
+            a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16; a.lnfix_c1 = w.cq_f.c1; a.lnfix_c2 = w.cq_f.c2;
             a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
         }
         DBG_GATE(e);
         HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
         g = GemmArgs();
-        g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->attn_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
+        g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.attn_frag;
+        g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         // LN3 + fc1 + GELU(erf) -> fragments ; fc2 + residual (M:486-492)
         g = GemmArgs();
         g.W = w.fc1.ptr; g.N = F; g.K = D; g.M = M;
-        g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = D; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.eps = 1e-5f;
+        g.pro = PRO_LAYERNORM; g.x = wk.x; g.ldx = D; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.eps = 1e-5f;
         use_fold(e, &g, w.fc1_f, 2);
-        g.epi = EPI_ACT_FRAG; g.act = ACT_GELU; g.ofrag = e->mlp_frag; g.ldo = F;
+        g.epi = EPI_ACT_FRAG; g.act = ACT_GELU; g.ofrag = wk.mlp_frag; g.ldo = F;
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
         g = GemmArgs();
-        g.W = w.fc2.ptr; g.N = D; g.K = F; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->mlp_frag;
-        g.epi = EPI_RESIDUAL; g.out = e->x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
-        if (e->look2_active && l + 1 < c.layers) {
+        g.W = w.fc2.ptr; g.N = D; g.K = F; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.mlp_frag;
+        g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
+        if (e->look2_active && npos == 0 && l + 1 < c.layers) {
             // look-ahead QKV of layer l+1: LN1(x + g.W2^T).Wqkv^T = rstd * ((x.Wqkv'^T + g.(Wqkv'.W2)^T) - mean * c1) + c2;
             // extra workgroups of this launch compute the raw product from the rows it starts from (x fragments) and its
             // own input (GELU fragments); the new rows go to the other fragment buffer, their statistics to `xstat`
-            void* next = e->xf_cur == e->x_frag ? e->x_frag2 : e->x_frag;
+            void* next = e->xf_cur == wk.x_frag ? wk.x_frag2 : wk.x_frag;
             g.W2 = w.look2; g.N2 = 3 * D; g.K2 = D + F; g.xfrag_lo = e->xf_cur; g.ksplit = D / (e->dt == PTTS_DTYPE_BF16 ? 32 : 16);
-            g.out2 = e->qkv_raw; g.ldo2 = 3 * D; g.xfrag_out = next; g.xstat = e->xstat;
+            g.out2 = e->qkv_raw; g.ldo2 = 3 * D; g.xfrag_out = next; g.xstat = wk.xstat;
             g.wide2 = e->look2_wide ? 1 : 0;
             e->xf_cur = next;
         }
@@ -440,7 +469,7 @@ int run_forward_half(ptts_engine* e, hipStream_t s, bool profile) {
     DBG_GATE(e);
     e->xf_cur = e->x_frag;
     HIP_TRY(embed_codebooks_launch(embed_args(e), e->B_eff, e->dt, s));
-    PTTS_TRY(run_layers(e, s, profile));
+    PTTS_TRY(run_layers(e, s, profile, decode_work(e), e->B_eff));
     DBG_GATE(e);
     // final LayerNorm (M:959) + the K LM heads (M:1143)
     GemmArgs g;
@@ -750,6 +779,8 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     if (const char* v = getenv("PTTS_LOOKAHEAD2_WIDE")) e->look2_wide = atoi(v) != 0;
     if (const char* v = getenv("PTTS_FOLD_MASK")) e->fold_mask = atoi(v);
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
+    e->seq_prefill = getenv("PTTS_PREFILL_SEQ") != nullptr && atoi(getenv("PTTS_PREFILL_SEQ")) != 0;
+    if (const char* v = getenv("PTTS_PREFILL_CHUNK")) { e->pf_chunk = atoi(v); if (e->pf_chunk < 1) e->pf_chunk = 1; }
     if (cfg->dac_hidden > 0) {
         if (cfg->dac_n_up <= 0 || cfg->dac_n_up > 8 || cfg->dac_hidden % (16 << cfg->dac_n_up) != 0 || cfg->dac_latent % 16 != 0) {
             delete e;
@@ -874,6 +905,8 @@ int ptts_destroy(ptts_engine* e) {
     drop_graph(e);
     if (e->dac_buf0) (void)hipFree(e->dac_buf0);
     if (e->dac_buf1) (void)hipFree(e->dac_buf1);
+    for (void* p : {(void*)e->pf.x, (void*)e->pf.q, (void*)e->pf.xstat, e->pf.attn_frag, e->pf.mlp_frag, e->pf.x_frag, e->pf.x_frag2})
+        if (p) (void)hipFree(p);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (void* p : e->allocs) (void)hipFree(p);
@@ -1105,27 +1138,80 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     std::vector<int> ones(B * c.codebooks, 1);
     HIP_TRY(hipMemcpyAsync(e->unfinished, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
-    // the P prompt positions, one cached position at a time (causal attention == incremental decode)
-    for (int p = 0; p < P; ++p) {
-        if (e->dbg_stop >= 0 && e->dbg_count >= e->dbg_stop) break;
-        e->dbg_count++;
-        e->xf_cur = e->x_frag;
-        HIP_TRY(embed_prompt_launch(embed_args(e), B_eff, e->dt, s));
-        e->host_pos = p;
-        PTTS_TRY(run_layers(e, s, false));
-        if (e->dbg_stop >= 0 && e->dbg_count >= e->dbg_stop) break;
-        HIP_TRY(advance_prompt_launch(e->state, s));
-    }
-    // decoder prefix (user `decoder_input_ids` longer than the start column, M:2150-2195): its columns 0 .. start_len-2 go
-    // through the cache like prompt positions; the delay-pattern mask holds every prefix value (M:108-111), so the
-    // masked column IS the model input, and nothing is sampled or latched for these columns
-    for (int j = 0; j + 1 < start_len; ++j) {
-        HIP_TRY(init_tokens_launch(e->raw_ids, e->pattern, e->tok_in, B * c.codebooks, B_eff * c.codebooks, L, j, s));
-        e->xf_cur = e->x_frag;
-        HIP_TRY(embed_codebooks_launch(embed_args(e), B_eff, e->dt, s));
-        e->host_pos = P + j;
-        PTTS_TRY(run_layers(e, s, false));
-        HIP_TRY(advance_prompt_launch(e->state, s));
+    const int n_prefix = start_len - 1;     // decoder prefix columns (user `decoder_input_ids`, M:2150-2195) behind the prompt
+    if (e->seq_prefill || e->dbg_stop >= 0) {
+        // round-1 form (PTTS_PREFILL_SEQ=1; also the kernel-by-kernel debug hooks): the P prompt positions, then the prefix
+        // columns, one cached position at a time through the decode kernels (causal attention == incremental decode)
+        const Work wk = decode_work(e);
+        for (int p = 0; p < P; ++p) {
+            if (e->dbg_stop >= 0 && e->dbg_count >= e->dbg_stop) break;
+            e->dbg_count++;
+            e->xf_cur = e->x_frag;
+            HIP_TRY(embed_prompt_launch(embed_args(e), B_eff, e->dt, s));
+            e->host_pos = p;
+            PTTS_TRY(run_layers(e, s, false, wk, B_eff));
+            if (e->dbg_stop >= 0 && e->dbg_count >= e->dbg_stop) break;
+            HIP_TRY(advance_prompt_launch(e->state, s));
+        }
+        // the delay-pattern mask holds every prefix value (M:108-111), so the masked column IS the model input, and
+        // nothing is sampled or latched for these columns
+        for (int j = 0; j < n_prefix; ++j) {
+            HIP_TRY(init_tokens_launch(e->raw_ids, e->pattern, e->tok_in, B * c.codebooks, B_eff * c.codebooks, L, j, s));
+            e->xf_cur = e->x_frag;
+            HIP_TRY(embed_codebooks_launch(embed_args(e), B_eff, e->dt, s));
+            e->host_pos = P + j;
+            PTTS_TRY(run_layers(e, s, false, wk, B_eff));
+            HIP_TRY(advance_prompt_launch(e->state, s));
+        }
+    } else if (P + n_prefix > 0) {
+        // Batched prefill (reference M:794-978 runs all P + prefix positions in ONE forward under the 4-D causal mask,
+        // M:839-840, M:870-872): chunks of up to pf_chunk positions x B_eff utterances go through the layer stack as
+        // M = B_eff * npos rows - MFMA GEMMs over every row at once, k / v of every row appended by the QKV epilogue, causal
+        // attention over the cache.  Prompt rows and prefix rows differ only in their embedding.
+        int chunk = e->pf_chunk;
+        const int max_rows = 16384;                       // workspace bound: ~0.4 GB of activations at mini_v0.1 widths
+        if (chunk * B_eff > max_rows) chunk = max_rows / B_eff > 0 ? max_rows / B_eff : 1;
+        const int total = P + n_prefix;
+        const int need_rows = ((B_eff * (total < chunk ? total : chunk)) + 31) / 32 * 32;
+        if (need_rows > e->pf.rows) {
+            HIP_TRY(hipStreamSynchronize(s));
+            Work& w = e->pf;
+            for (void* p : {(void*)w.x, (void*)w.q, (void*)w.xstat, w.attn_frag, w.mlp_frag, w.x_frag, w.x_frag2})
+                if (p) (void)hipFree(p);
+            w = Work();
+            const size_t D_ = c.hidden, F_ = c.ffn, R = need_rows;
+            bool ok = hipMalloc((void**)&w.x, sizeof(float) * R * D_) == hipSuccess &&
+                      hipMalloc((void**)&w.q, sizeof(float) * R * D_) == hipSuccess &&
+                      hipMalloc((void**)&w.xstat, sizeof(float) * 2 * R * (D_ / 16 + 1)) == hipSuccess &&
+                      hipMalloc(&w.attn_frag, e->esz * R * D_) == hipSuccess &&
+                      hipMalloc(&w.mlp_frag, e->esz * R * F_) == hipSuccess &&
+                      hipMalloc(&w.x_frag, e->esz * R * D_) == hipSuccess &&
+                      hipMalloc(&w.x_frag2, e->esz * R * D_) == hipSuccess;
+            if (!ok) return fail(PTTS_E_NOMEM, "prefill workspace for %d rows", need_rows);
+            w.rows = need_rows;
+            // rows of the last m-tile beyond M are read as MFMA operands (their results are never stored): keep them finite
+            HIP_TRY(hipMemsetAsync(w.attn_frag, 0, e->esz * R * D_, s));
+            HIP_TRY(hipMemsetAsync(w.mlp_frag, 0, e->esz * R * F_, s));
+            HIP_TRY(hipMemsetAsync(w.x_frag, 0, e->esz * R * D_, s));
+            HIP_TRY(hipMemsetAsync(w.x_frag2, 0, e->esz * R * D_, s));
+            HIP_TRY(hipMemsetAsync(w.x, 0, sizeof(float) * R * D_, s));
+        }
+        const Work& wk = e->pf;
+        auto run_chunk = [&](int pos0, int npos, bool prompt_rows) -> int {
+            EmbedArgs ea = embed_args(e);
+            ea.x = wk.x; ea.xfrag = e->fold_ln ? wk.x_frag : nullptr;
+            if (prompt_rows) HIP_TRY(embed_prompt_rows_launch(ea, B_eff, npos, pos0, e->dt, s));
+            else HIP_TRY(embed_prefix_rows_launch(ea, B_eff, npos, pos0, pos0 - P, (const long long*)e->raw_ids, e->pattern,
+                                                  B * c.codebooks, L, e->dt, s));
+            e->xf_cur = wk.x_frag;
+            e->host_pos = pos0 + npos - 1;
+            return run_layers(e, s, false, wk, B_eff * npos, npos, pos0);
+        };
+        for (int p0 = 0; p0 < P; p0 += chunk) PTTS_TRY(run_chunk(p0, (P - p0 < chunk) ? P - p0 : chunk, true));
+        for (int j0 = 0; j0 < n_prefix; j0 += chunk) PTTS_TRY(run_chunk(P + j0, (n_prefix - j0 < chunk) ? n_prefix - j0 : chunk, false));
+        st.pos = P + n_prefix;
+        HIP_TRY(hipMemcpyAsync(e->state, &st, sizeof(st), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));   // `st` lives on this stack frame
     }
     e->host_pos = P + start_len - 1;
     e->host_cur = start_len;

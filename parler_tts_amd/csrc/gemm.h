@@ -53,6 +53,9 @@ struct GemmArgs {
     const StepState* state = nullptr;
     int D = 0;                    // model width (segment size of the fused QKV / KV projection)
     int T = 1;                    // cross rows per utterance (row = b*T + t)
+    // EPI_QKV_SELF in a batched prefill chunk: row = b * npos + i is cache position pos0 + i of utterance b
+    // (npos = 0: decode, row = utterance, position = state->pos)
+    int npos = 0, pos0 = 0;
 };
 
 hipError_t gemm_init();

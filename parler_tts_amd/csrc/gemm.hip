@@ -152,8 +152,10 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
                 kv = seg - 1;
             }
             int b, tok;
-            if (a.epi == EPI_QKV_SELF) { b = row; tok = a.state->pos; }
-            else { b = row / a.T; tok = row - b * a.T; }
+            if (a.epi == EPI_QKV_SELF) {
+                if (a.npos > 0) { b = row / a.npos; tok = a.pos0 + (row - b * a.npos); }
+                else { b = row; tok = a.state->pos; }
+            } else { b = row / a.T; tok = row - b * a.T; }
             elem_t* c = reinterpret_cast<elem_t*>(a.pool.base) +
                         a.pool.elem_off(b, a.layer, kv, nn >> 6, tok) + (nn & 63);
 #pragma unroll

@@ -39,6 +39,12 @@ struct SelectArgs {
 hipError_t embed_codebooks_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s);
 hipError_t embed_prompt_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s);
 hipError_t advance_prompt_launch(StepState* st, hipStream_t s);
+// batched prefill: rows b * npos + i of x (+ fragments) for the chunk's positions pos0 .. pos0 + npos - 1.
+// prompt rows: embed_prompts[prompt_ids[b][pos]] (or the pre-embedded row) + pos_table[pos];
+// prefix rows (decoder_input_ids columns): sum_k embed_tokens[k][masked id of column col0 + i] + pos_table[pos0 + i]
+hipError_t embed_prompt_rows_launch(const EmbedArgs& a, int B, int npos, int pos0, int dtype, hipStream_t s);
+hipError_t embed_prefix_rows_launch(const EmbedArgs& a, int B, int npos, int pos0, int col0, const long long* raw_ids,
+                                    const long long* pattern, int rows_src, int L, int dtype, hipStream_t s);
 hipError_t select_launch(const SelectArgs& a, hipStream_t s);
 hipError_t advance_launch(StepState* st, const int* unfinished, int rows, int L, hipStream_t s);
 hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,

@@ -80,6 +80,51 @@ __global__ void embed_prompt_kernel(EmbedArgs a) {
 
 __global__ void advance_prompt_kernel(StepState* s) { s->pos += 1; }
 
+// batched prefill, prompt rows: one block per (utterance b, chunk position i)
+template <typename P>
+__global__ void embed_prompt_rows_kernel(EmbedArgs a, int npos, int pos0) {
+    typedef typename P::elem_t elem_t;
+    const int b = blockIdx.x / npos, i = blockIdx.x - b * npos, pos = pos0 + i;
+    const int row = blockIdx.x;
+    const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)pos * a.D;
+    elem_t* xf = a.xfrag ? reinterpret_cast<elem_t*>(a.xfrag) + (size_t)(row >> 5) * 32 * a.D : nullptr;
+    const float* pre = a.prompt_embeds ? a.prompt_embeds + ((size_t)b * a.P + pos) * a.D : nullptr;
+    const elem_t* prow = pre ? nullptr
+                             : reinterpret_cast<const elem_t*>(a.prompt_table) + (size_t)a.prompt_ids[(size_t)b * a.P + pos] * a.D;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+        const float v = (pre ? pre[d] : from_elem<P>(prow[d])) + from_elem<P>(ptab[d]);
+        a.x[(size_t)row * a.D + d] = v;
+        if (xf) xf[frag_off<P>(row & 31, d)] = to_elem<P>(v);
+    }
+}
+
+// batched prefill, decoder-prefix rows: the masked ids of column col0 + i (apply_delay_pattern_mask, M:68-74) summed over the
+// codebooks strictly left to right (M:836) + the position row
+template <typename P>
+__global__ void embed_prefix_rows_kernel(EmbedArgs a, int npos, int pos0, int col0, const long long* raw_ids,
+                                         const long long* pattern, int rows_src, int L) {
+    typedef typename P::elem_t elem_t;
+    __shared__ int toks[32];
+    const int b = blockIdx.x / npos, i = blockIdx.x - b * npos;
+    const int row = blockIdx.x, col = col0 + i;
+    if ((int)threadIdx.x < a.K) {
+        const int src = (b * a.K + (int)threadIdx.x) % rows_src;      // guidance: the null half repeats the ids (M:2112)
+        const long long f = pattern[(size_t)src * L + col];
+        toks[threadIdx.x] = (int)(f == -1 ? raw_ids[(size_t)src * L + col] : f);
+    }
+    __syncthreads();
+    const elem_t* tab = reinterpret_cast<const elem_t*>(a.tables);
+    const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)(pos0 + i) * a.D;
+    elem_t* xf = a.xfrag ? reinterpret_cast<elem_t*>(a.xfrag) + (size_t)(row >> 5) * 32 * a.D : nullptr;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < a.K; ++k) s = s + from_elem<P>(tab[((size_t)k * a.rows + toks[k]) * a.D + d]);
+        const float v = s + from_elem<P>(ptab[d]);
+        a.x[(size_t)row * a.D + d] = v;
+        if (xf) xf[frag_off<P>(row & 31, d)] = to_elem<P>(v);
+    }
+}
+
 // ---- Philox4x32-10 counter RNG (one draw per (row, step)) ----
 __device__ inline void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
@@ -467,6 +512,19 @@ hipError_t embed_codebooks_launch(const EmbedArgs& a, int B, int dtype, hipStrea
 hipError_t embed_prompt_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s) {
     if (dtype == PTTS_BF16) hipLaunchKernelGGL(embed_prompt_kernel<PBF16>, dim3(B), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(embed_prompt_kernel<PF32>, dim3(B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t embed_prompt_rows_launch(const EmbedArgs& a, int B, int npos, int pos0, int dtype, hipStream_t s) {
+    if (dtype == PTTS_BF16) hipLaunchKernelGGL(embed_prompt_rows_kernel<PBF16>, dim3(B * npos), dim3(256), 0, s, a, npos, pos0);
+    else hipLaunchKernelGGL(embed_prompt_rows_kernel<PF32>, dim3(B * npos), dim3(256), 0, s, a, npos, pos0);
+    return hipGetLastError();
+}
+hipError_t embed_prefix_rows_launch(const EmbedArgs& a, int B, int npos, int pos0, int col0, const long long* raw_ids,
+                                    const long long* pattern, int rows_src, int L, int dtype, hipStream_t s) {
+    if (dtype == PTTS_BF16)
+        hipLaunchKernelGGL(embed_prefix_rows_kernel<PBF16>, dim3(B * npos), dim3(256), 0, s, a, npos, pos0, col0, raw_ids, pattern, rows_src, L);
+    else
+        hipLaunchKernelGGL(embed_prefix_rows_kernel<PF32>, dim3(B * npos), dim3(256), 0, s, a, npos, pos0, col0, raw_ids, pattern, rows_src, L);
     return hipGetLastError();
 }
 hipError_t advance_prompt_launch(StepState* st, hipStream_t s) {

