@@ -476,29 +476,36 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_causal_kernel(AttnArgs a, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Full (bidirectional) attention for the T5 encoder: T <= 512 tokens, one workgroup per (head, b).
+// Full (bidirectional) attention for the T5 encoder: one workgroup per (head, b); any T the LDS score rows hold (thousands).
 // scores = q.k (no scaling) + rel-pos bias[h][bucket(j - i)] + (1 - mask_j) * finfo.min; softmax fp32.
 // (HF:models/t5/modeling_t5.py:144-173, 217-280.)  q/k/v row-major fp32 [B*T][3*inner] as written by
 // the QKV projection; output in fragment order for the `o` projection.
 // ------------------------------------------------------------------------------------------------
-template <typename OP>
+// LDSKV = true: K and V of the (head, utterance) are parked in LDS (fits up to T ~ 300 at d_kv 64); false: they are read
+// from the fp32 QKV rows in global memory (L2-resident: T x 3 x inner floats per utterance), for descriptions up to the
+// 512 tokens T5 accepts.  Same arithmetic and summation order either way.
+template <typename OP, bool LDSKV>
 __global__ __launch_bounds__(256) void attn_full_kernel(FullAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = a.T, dk = a.dk;
-    float* ks = reinterpret_cast<float*>(smem);          // [T][dk+1]
-    float* vs = ks + T * (dk + 1);                       // [T][dk+1]
-    float* pr = vs + T * (dk + 1);                       // [4 waves][T] probabilities of the wave's query
+    float* ks = reinterpret_cast<float*>(smem);          // [T][dk+1]   (LDSKV only)
+    float* vs = ks + (LDSKV ? T * (dk + 1) : 0);         // [T][dk+1]
+    float* pr = vs + (LDSKV ? T * (dk + 1) : 0);         // [4 waves][T] probabilities of the wave's query
     float* qs = pr + 4 * T;                              // [4][dk]
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int inner = a.H * dk;
     const float* base = a.qkv + (size_t)b * T * a.ld;
-    for (int i = tid; i < T * dk; i += 256) {
-        int t = i / dk, d = i % dk;
-        ks[t * (dk + 1) + d] = base[(size_t)t * a.ld + inner + h * dk + d];
-        vs[t * (dk + 1) + d] = base[(size_t)t * a.ld + 2 * inner + h * dk + d];
+    const float* kg = base + inner + h * dk;             // K row j at kg + j * ld
+    const float* vg = base + 2 * inner + h * dk;
+    if (LDSKV) {
+        for (int i = tid; i < T * dk; i += 256) {
+            int t = i / dk, d = i % dk;
+            ks[t * (dk + 1) + d] = kg[(size_t)t * a.ld + d];
+            vs[t * (dk + 1) + d] = vg[(size_t)t * a.ld + d];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int* mask = a.mask ? a.mask + (size_t)b * T : nullptr;
     for (int qi = w; qi < T; qi += 4) {
         for (int d = lane; d < dk; d += 64) qs[w * dk + d] = base[(size_t)qi * a.ld + h * dk + d];
@@ -506,7 +513,16 @@ __global__ __launch_bounds__(256) void attn_full_kernel(FullAttnArgs a) {
         float mx = -INFINITY;
         for (int j = lane; j < T; j += 64) {
             float s = 0.f;
-            for (int d = 0; d < dk; ++d) s = fmaf(qs[w * dk + d], ks[j * (dk + 1) + d], s);
+            if (LDSKV) {
+                for (int d = 0; d < dk; ++d) s = fmaf(qs[w * dk + d], ks[j * (dk + 1) + d], s);
+            } else {
+                const float4* kr = reinterpret_cast<const float4*>(kg + (size_t)j * a.ld);
+                for (int d = 0; d < dk; d += 4) {
+                    const float4 kv = kr[d >> 2];
+                    s = fmaf(qs[w * dk + d], kv.x, s); s = fmaf(qs[w * dk + d + 1], kv.y, s);
+                    s = fmaf(qs[w * dk + d + 2], kv.z, s); s = fmaf(qs[w * dk + d + 3], kv.w, s);
+                }
+            }
             s = s * a.scale;
             s = s + a.rel_bias[(size_t)h * a.n_rel + (j - qi + T - 1)];
             if (mask) s = s + (1.0f - (float)mask[j]) * -3.4028234663852886e38f;
@@ -524,7 +540,11 @@ __global__ __launch_bounds__(256) void attn_full_kernel(FullAttnArgs a) {
         __builtin_amdgcn_wave_barrier();
         for (int d = lane; d < dk; d += 64) {
             float o = 0.f;
-            for (int j = 0; j < T; ++j) o = fmaf(pr[w * T + j] / sum, vs[j * (dk + 1) + d], o);
+            if (LDSKV) {
+                for (int j = 0; j < T; ++j) o = fmaf(pr[w * T + j] / sum, vs[j * (dk + 1) + d], o);
+            } else {
+                for (int j = 0; j < T; ++j) o = fmaf(pr[w * T + j] / sum, vg[(size_t)j * a.ld + d], o);   // lanes read one row: coalesced
+            }
             int row = b * T + qi;
             typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(row >> 5) * 32 * inner;
             of[frag_off<OP>(row & 31, h * dk + d)] = to_elem<OP>(o);
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(FullAttnArgs a) {
 }  // namespace
 
 hipError_t attn_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PBF16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PBF16, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     const void* causal[4] = {reinterpret_cast<const void*>(attn_causal_kernel<PBF16, PBF16>),
@@ -547,7 +567,7 @@ hipError_t attn_init() {
         e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PF32>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PF32, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -605,9 +625,18 @@ hipError_t attn_causal_launch(const AttnArgs& a, int B, int H, int cache_dtype, 
 
 hipError_t attn_full_launch(const FullAttnArgs& a, int B, int out_dtype, hipStream_t stream) {
     size_t lds = ((size_t)2 * a.T * (a.dk + 1) + 4 * a.T + 4 * a.dk) * sizeof(float);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.H, B), block(256);
-    if (out_dtype == PTTS_BF16) hipLaunchKernelGGL(attn_full_kernel<PBF16>, grid, block, lds, stream, a);
-    else hipLaunchKernelGGL(attn_full_kernel<PF32>, grid, block, lds, stream, a);
+    const bool force_global = getenv("PTTS_T5_GLOBAL_KV") != nullptr;      // A/B and tests of the long-description path
+    if (lds <= 160 * 1024 && !force_global) {
+        if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_full_kernel<PBF16, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((attn_full_kernel<PF32, true>), grid, block, lds, stream, a);
+        return hipGetLastError();
+    }
+    // K / V of this (head, utterance) exceed the LDS (T > ~300 at d_kv = 64): read them from the QKV rows in global memory
+    if (a.dk % 4 != 0 || a.ld % 4 != 0) return hipErrorInvalidValue;
+    lds = ((size_t)4 * a.T + 4 * a.dk) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_full_kernel<PBF16, false>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_full_kernel<PF32, false>), grid, block, lds, stream, a);
     return hipGetLastError();
 }

@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """The CPU oracles run small matrices (tiny fixtures) and a few big ones (mini_v0.1 widths): on a many-core GPU host the
+    default of one torch thread per core makes the small ones crawl (118 s vs 12 s for the 2580-column tiny restatement)."""
+    import torch
+
+    n = os.cpu_count() or 8
+    torch.set_num_threads(max(1, min(16, n)))
+    yield

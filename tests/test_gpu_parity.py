@@ -451,6 +451,43 @@ def test_t5_encoder(hip, name, dtype, tol):
     assert np.abs(enc - f["enc_t5"])[valid].max() < tol
 
 
+def test_t5_encoder_long_description_up_to_512_tokens(hip):
+    """Descriptions longer than the ~300 tokens whose K / V fit the LDS (T5 accepts 512): the attention kernel reads K / V
+    from the QKV rows in global memory instead.  T = 400 and T = 512 with right padding, fp32 engine vs the oracle's
+    T5EncoderModel restatement; and the global-memory variant forced at a short length must equal the LDS variant."""
+    from oracle import cpu_ref
+    from parler_tts_amd.configuration import tiny_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=11, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+    _models.clear()
+    torch.cuda.empty_cache()
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device="cuda:0")
+    g = torch.Generator().manual_seed(2)
+    for T in (400, 512):
+        desc = torch.randint(2, cfg.text_encoder.vocab_size, (2, T), generator=g)
+        amask = torch.ones(2, T, dtype=torch.long)
+        amask[1, T - 37:] = 0
+        eng = model.engine(2, T, 4, 16)
+        got = eng.t5_encode(desc, amask).cpu()
+        want = cpu_ref.t5_encode(cfg, sd, desc, amask)
+        assert ((got - want).abs() * amask[..., None]).max() < 5e-4, T
+    desc = torch.randint(2, cfg.text_encoder.vocab_size, (2, 40), generator=g)
+    amask = torch.ones(2, 40, dtype=torch.long)
+    eng = model.engine(2, 40, 4, 16)
+    a = eng.t5_encode(desc, amask).cpu()
+    os.environ["PTTS_T5_GLOBAL_KV"] = "1"
+    try:
+        b = eng.t5_encode(desc, amask).cpu()
+    finally:
+        del os.environ["PTTS_T5_GLOBAL_KV"]
+    assert (a - b).abs().max() < 1e-6
+    del model
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------
 # sampling
 # ------------------------------------------------------------------------------------------------
