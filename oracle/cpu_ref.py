@@ -195,7 +195,7 @@ def decoder_forward(
             mask2d = torch.cat([prompt_attention_mask, torch.ones(B, gen_len, dtype=prompt_attention_mask.dtype)], 1)
     self_mask = causal_4d_mask(mask2d, B, tq, past, dtype)       # M:870-872
     cross_mask = None
-    if encoder_attention_mask is not None:                       # M:875-879
+    if encoder_attention_mask is not None and encoder_hidden_states is not None:                       # M:875-879
         inv = 1.0 - encoder_attention_mask[:, None, None, :].to(dtype).expand(B, 1, tq, -1)
         cross_mask = inv.masked_fill(inv.bool(), _finfo_min(dtype))
 
@@ -203,7 +203,7 @@ def decoder_forward(
     x = x + pos                                                   # M:886
     scaling = hd ** -0.5
 
-    first = len(cache.cross_k) == 0
+    first = cache.length == 0 and len(cache.self_k) == 0
     for l in range(L):
         p = f"{pre}layers.{l}."
         # --- self attention, M:445-460 ---
@@ -230,15 +230,16 @@ def decoder_forward(
             v = cache.self_v[l][:, :, : past + tq]
         a = _attention(_shape(q, B, H, hd), k, v, self_mask, B, H, hd)
         x = res + F.linear(a, sd[p + "self_attn.out_proj.weight"])
-        # --- cross attention, M:462-483 ---
-        res = x
-        h = F.layer_norm(x, (D,), sd[p + "encoder_attn_layer_norm.weight"], sd[p + "encoder_attn_layer_norm.bias"])
-        q = F.linear(h, sd[p + "encoder_attn.q_proj.weight"]) * scaling
-        if first:                                                        # M:295-298
-            cache.cross_k.append(_shape(F.linear(encoder_hidden_states, sd[p + "encoder_attn.k_proj.weight"]), B, H, hd))
-            cache.cross_v.append(_shape(F.linear(encoder_hidden_states, sd[p + "encoder_attn.v_proj.weight"]), B, H, hd))
-        a = _attention(_shape(q, B, H, hd), cache.cross_k[l], cache.cross_v[l], cross_mask, B, H, hd)
-        x = res + F.linear(a, sd[p + "encoder_attn.out_proj.weight"])
+        # --- cross attention, M:462-483 (the whole block is skipped without encoder states, M:465) ---
+        if encoder_hidden_states is not None:
+            res = x
+            h = F.layer_norm(x, (D,), sd[p + "encoder_attn_layer_norm.weight"], sd[p + "encoder_attn_layer_norm.bias"])
+            q = F.linear(h, sd[p + "encoder_attn.q_proj.weight"]) * scaling
+            if first:                                                        # M:295-298
+                cache.cross_k.append(_shape(F.linear(encoder_hidden_states, sd[p + "encoder_attn.k_proj.weight"]), B, H, hd))
+                cache.cross_v.append(_shape(F.linear(encoder_hidden_states, sd[p + "encoder_attn.v_proj.weight"]), B, H, hd))
+            a = _attention(_shape(q, B, H, hd), cache.cross_k[l], cache.cross_v[l], cross_mask, B, H, hd)
+            x = res + F.linear(a, sd[p + "encoder_attn.out_proj.weight"])
         # --- MLP, M:485-492 ---
         res = x
         h = F.layer_norm(x, (D,), sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
@@ -335,13 +336,16 @@ def generate_ids(
 
     dec = cfg.decoder
     K = dec.num_codebooks
-    B = encoder_states.shape[0]
     pad, eos, bos = dec.pad_token_id, dec.eos_token_id, dec.bos_token_id
     use_cfg = guidance_scale is not None and guidance_scale > 1
+    if decoder_only:     # M:1218-1232: the driver doubles ids and prompt only; encoder states come with 2B rows, or not at all
+        B = prompt_hidden_states.shape[0] if prompt_hidden_states is not None else encoder_states.shape[0] // (2 if use_cfg else 1)
+    else:
+        B = encoder_states.shape[0]
 
     enc = encoder_states
     amask = attention_mask
-    if use_cfg:  # M:2231-2237
+    if use_cfg and not decoder_only:  # M:2231-2237
         enc = torch.cat([enc, torch.zeros_like(enc)], dim=0)
         if amask is not None:
             amask = torch.cat([amask, torch.zeros_like(amask)], dim=0)
@@ -349,7 +353,12 @@ def generate_ids(
     if prompt_hidden_states is not None:          # pre-embedded prompt (M:2476; the decoder-only driver's only form)
         prompt_h = prompt_hidden_states
     pmask = prompt_attention_mask
-    if use_cfg:  # M:2109-2118
+    if use_cfg and decoder_only:  # M:1218-1232: zeroed prompt under an all-zero prompt mask for the null half
+        if prompt_h is not None:
+            prompt_h = torch.cat([prompt_h, torch.zeros_like(prompt_h)], dim=0)
+        if pmask is not None:
+            pmask = torch.cat([pmask, torch.zeros_like(pmask)], dim=0)
+    elif use_cfg:  # M:2109-2118
         if prompt_h is not None:
             prompt_h = prompt_h.repeat(2, 1, 1)
         if pmask is not None:

@@ -297,8 +297,43 @@ def nrs_case():
              temperature=0.7, top_k=50, generator=g, num_return_sequences=2)
 
 
+def causal_variants():
+    """decoder-only driver, the two call shapes round 1 refused: classifier-free guidance (M:1218-1232: ids and prompt doubled
+    by the driver, encoder states doubled by the caller) and no encoder states at all (no cross-attention block, M:465)."""
+    tiny = tiny_config()
+    sd_kw = dict(seed=11, never_eos=True, ln_jitter=0.1)
+    sd = synthetic_state_dict(tiny, parts=("text_encoder", "decoder"), **sd_kw)
+    causal = ref_shim.build_reference_model(tiny, sd).decoder
+    B, T, P, L, D = 2, 9, 5, 22, tiny.decoder.hidden_size
+    for name, gs, with_enc in (("tiny_causal_cfg", 3.0, True), ("tiny_causal_noenc", None, False)):
+        for seed_in in range(500, 560):
+            g = torch.Generator().manual_seed(seed_in)
+            rows = B * (2 if gs else 1)
+            enc_h = torch.randn(rows, T, D, generator=g) if with_enc else None
+            emask = torch.ones(rows, T, dtype=torch.long) if with_enc else None
+            if with_enc:
+                emask[1, T - 3:] = 0
+                enc_h[B:] = 0 if gs else enc_h[B:]              # the caller's null half
+            prompt_h = torch.randn(B, P, D, generator=g) * 0.05
+            pmask = torch.ones(B, P, dtype=torch.long)
+            pmask[1, :2] = 0
+            r = ref_shim.reference_causal_generate_ids(causal, enc_h, emask, prompt_h, pmask, L, record_logits=64, guidance_scale=gs)
+            fm = free_margin(r)
+            if fm >= 1e-3:
+                break
+        else:
+            raise RuntimeError("no seed met the margin")
+        print(f"  {name}: seed_in={seed_in} free-min margin {fm:.3e}")
+        extra = dict(enc_h=enc_h, emask=emask) if with_enc else {}
+        save(name, prompt_h=prompt_h, pmask=pmask, max_length=L, free_min_margin=fm,
+             meta=json.dumps(dict(sd_kw=sd_kw, B=B, T=T, P=P, L=L, seed_in=seed_in, guidance_scale=gs)), **extra, **r)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-causal-variants" in sys.argv:
+        causal_variants()
+        return
     if "--only-long" in sys.argv:
         torch.set_num_threads(8)
         long_cases()

@@ -213,15 +213,19 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
 
 @torch.no_grad()
 def reference_causal_generate_ids(causal, encoder_hidden_states, encoder_attention_mask, prompt_hidden_states,
-                                  prompt_attention_mask, max_length, record_logits=0):
+                                  prompt_attention_mask, max_length, record_logits=0, guidance_scale=None):
     """The decoder-only driver (M:1281-1552) on the REAL ``ParlerTTSForCausalLM``: its ``forward`` (M:1096-1185) and
     ``prepare_inputs_for_generation`` (M:1187-1247) with the third-party greedy step restated as in
     ``reference_generate_ids``; un-delay per M:1532-1546."""
     dec = causal.config
     K = dec.num_codebooks
-    B = encoder_hidden_states.shape[0]
+    use_cfg = guidance_scale is not None and guidance_scale > 1
+    # under guidance the driver doubles only the decoder ids and the prompt (M:1218-1232): the caller passes encoder states
+    # with 2 x batch rows; without encoder states the layers skip their cross-attention block (M:465)
+    B = prompt_hidden_states.shape[0] if prompt_hidden_states is not None else encoder_hidden_states.shape[0] // (2 if use_cfg else 1)
     kw = dict(encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
-              prompt_hidden_states=prompt_hidden_states, prompt_attention_mask=prompt_attention_mask, use_cache=True)
+              prompt_hidden_states=prompt_hidden_states, prompt_attention_mask=prompt_attention_mask, use_cache=True,
+              guidance_scale=guidance_scale)
     ids = torch.full((B * K, 1), dec.bos_token_id, dtype=torch.long)
     ids, pattern = causal.build_delay_pattern_mask(ids, dec.bos_token_id, dec.pad_token_id, max_length)
     unf = torch.ones(B * K, dtype=torch.long)
@@ -231,6 +235,9 @@ def reference_causal_generate_ids(causal, encoder_hidden_states, encoder_attenti
         out = causal(**mi, return_dict=True)
         past = out.past_key_values
         logits = out.logits[:, -1, :]
+        if use_cfg:          # ClassifierFreeGuidanceLogitsProcessor, appended at M:1475-1477
+            n = logits.shape[0] // 2
+            logits = logits[n:] + (logits[:n] - logits[n:]) * guidance_scale
         if step < record_logits:
             step_logits.append(logits.clone())
         t2 = torch.topk(logits, 2, dim=-1)[0]

@@ -25,4 +25,8 @@ def __getattr__(name):
         from . import modeling
 
         return getattr(modeling, name)
+    if name == "AudioStreamer":
+        from .streamer import AudioStreamer
+
+        return AudioStreamer
     raise AttributeError(name)

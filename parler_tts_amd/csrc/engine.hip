@@ -383,7 +383,8 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr));
         }
         // out_proj + residual (M:380, M:460)
-        const bool look = e->look_active;
+        const bool cross = e->T > 0;        // decoder-only driver without encoder_hidden_states: no cross-attention block (M:465)
+        const bool look = e->look_active && cross;
         g = GemmArgs();
         g.W = w.o.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.attn_frag;
         g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
@@ -399,7 +400,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
         }
         DBG_GATE(e);
         PTTS_TRY(launch_gemm(e, g, s));
-        if (!look) {
+        if (cross && !look) {
             // LN2 + cross-attention query (M:467-471)
             g = GemmArgs();
             g.W = w.cq.ptr; g.N = D; g.K = D; g.M = M;
@@ -409,24 +410,26 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             DBG_GATE(e);
             PTTS_TRY(launch_gemm(e, g, s));
         }
-        // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294)
-        a = AttnArgs();
-        a.q = wk.q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
-        a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS;
-        a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = wk.attn_frag; a.D = D;
-        a.no_page_kernel = e->no_page_kernel ? 1 : 0;
-        a.rows_per_utt = npos > 0 ? npos : 1;
-        if (look) {
-            a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16; a.lnfix_c1 = w.cq_f.c1; a.lnfix_c2 = w.cq_f.c2;
-            a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
+        if (cross) {
+            // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294)
+            a = AttnArgs();
+            a.q = wk.q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
+            a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS;
+            a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = wk.attn_frag; a.D = D;
+            a.no_page_kernel = e->no_page_kernel ? 1 : 0;
+            a.rows_per_utt = npos > 0 ? npos : 1;
+            if (look) {
+                a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16; a.lnfix_c1 = w.cq_f.c1; a.lnfix_c2 = w.cq_f.c2;
+                a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
+            }
+            DBG_GATE(e);
+            HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
+            g = GemmArgs();
+            g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.attn_frag;
+            g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
+            DBG_GATE(e);
+            PTTS_TRY(launch_gemm(e, g, s));
         }
-        DBG_GATE(e);
-        HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
-        g = GemmArgs();
-        g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.attn_frag;
-        g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
-        DBG_GATE(e);
-        PTTS_TRY(launch_gemm(e, g, s));
         // LN3 + fc1 + GELU(erf) -> fragments ; fc2 + residual (M:486-492)
         g = GemmArgs();
         g.W = w.fc1.ptr; g.N = F; g.K = D; g.M = M;
@@ -1083,11 +1086,12 @@ int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_id
 int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P, int32_t L, const float* enc_states,
                  const int32_t* attention_mask, const int64_t* prompt_ids, const int32_t* prompt_mask, const int64_t* pattern,
                  int64_t* raw_ids, int32_t start_len, void* stream) {
-    if (!e || !enc_states || !attention_mask || !pattern || !raw_ids) return fail(PTTS_E_INVALID, "null argument");
+    if (!e || !pattern || !raw_ids) return fail(PTTS_E_INVALID, "null argument");
+    if (T != 0 && (!enc_states || !attention_mask)) return fail(PTTS_E_INVALID, "null argument");
     PTTS_TRY(ptts_weights_ready(e));
     const ptts_config& c = e->cfg;
     if (B <= 0 || (B_eff != B && B_eff != 2 * B) || B_eff > c.max_batch) return fail(PTTS_E_INVALID, "B=%d B_eff=%d max_batch=%d", B, B_eff, c.max_batch);
-    if (T <= 0 || T > c.max_desc_len || P < 0 || P > c.max_prompt_len || L < 2 || L > c.max_length)
+    if (T < 0 || T > c.max_desc_len || P < 0 || P > c.max_prompt_len || L < 2 || L > c.max_length)
         return fail(PTTS_E_INVALID, "T=%d P=%d L=%d outside the engine limits (%d, %d, %d)", T, P, L, c.max_desc_len, c.max_prompt_len, c.max_length);
     if (P > 0 && !prompt_ids && !e->prompt_embeds) return fail(PTTS_E_INVALID, "prompt_ids missing");
     if (start_len < 1 || start_len >= L) return fail(PTTS_E_INVALID, "start_len=%d must be in [1, L)", start_len);
@@ -1103,32 +1107,34 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     e->pattern = (const long long*)pattern; e->raw_ids = (long long*)raw_ids; e->prompt_ids = (const long long*)prompt_ids;
     const int D = c.hidden, M = B_eff * T;
     // additive masks (M:870-879)
-    HIP_TRY(build_bias_launch(attention_mask, e->cross_bias, B_eff, T, e->cross_blocks * PTTS_PAGE_TOKENS, s));
+    if (T > 0) HIP_TRY(build_bias_launch(attention_mask, e->cross_bias, B_eff, T, e->cross_blocks * PTTS_PAGE_TOKENS, s));
     e->has_self_bias = prompt_mask != nullptr || e->dec_mask != nullptr;
     if (e->has_self_bias)   // n_mask = 0 zero-fills (no prompt mask: every prompt key is attended)
-        HIP_TRY(build_bias_launch(prompt_mask ? prompt_mask : attention_mask, e->self_bias, B_eff, prompt_mask ? P : 0, e->s_cap, s));
+        HIP_TRY(build_bias_launch(prompt_mask ? prompt_mask : e->dec_mask, e->self_bias, B_eff, prompt_mask ? P : 0, e->s_cap, s));
     if (e->dec_mask) {      // decoder_attention_mask over the prefix columns = cache positions P .. P + start_len - 1
         HIP_TRY(build_bias_segment_launch(e->dec_mask, e->self_bias, B_eff, start_len, e->s_cap, P, s));
         e->dec_mask = nullptr;
     }
-    // enc_to_dec_proj (+bias) then * attention_mask (M:2010-2017); rowmask index = b*T + t = flat mask index
-    const float* enc_h = enc_states;
-    GemmArgs g;
-    if (c.enc_hidden != c.hidden) {
-        g.W = e->enc_proj.ptr; g.N = D; g.K = c.enc_hidden; g.M = M; g.pro = PRO_ROWMAJOR; g.x = enc_states; g.ldx = c.enc_hidden;
-        g.epi = EPI_ROWMAJOR; g.out = e->enc_h; g.ldo = D; g.bias = e->enc_proj_bias; g.rowmask = attention_mask;
-        PTTS_TRY(launch_gemm(e, g, s));
-        enc_h = e->enc_h;
-    } else {   // no enc_to_dec_proj (M:2010-2014 is skipped), only the mask multiply
-        HIP_TRY(rowmask_mul_launch(enc_states, attention_mask, e->enc_h, M, D, s));
-        enc_h = e->enc_h;
-    }
-    // cross K/V of every layer into the cross pool (M:295-298)
-    for (int l = 0; l < c.layers; ++l) {
-        g = GemmArgs();
-        g.W = e->layers[l].ckv.ptr; g.N = 2 * D; g.K = D; g.M = M; g.pro = PRO_ROWMAJOR; g.x = enc_h; g.ldx = D;
-        g.epi = EPI_KV_CROSS; g.pool = make_pool(e, true); g.layer = l; g.D = D; g.T = T;
-        PTTS_TRY(launch_gemm(e, g, s));
+    if (T > 0) {
+        // enc_to_dec_proj (+bias) then * attention_mask (M:2010-2017); rowmask index = b*T + t = flat mask index
+        const float* enc_h = enc_states;
+        GemmArgs g;
+        if (c.enc_hidden != c.hidden) {
+            g.W = e->enc_proj.ptr; g.N = D; g.K = c.enc_hidden; g.M = M; g.pro = PRO_ROWMAJOR; g.x = enc_states; g.ldx = c.enc_hidden;
+            g.epi = EPI_ROWMAJOR; g.out = e->enc_h; g.ldo = D; g.bias = e->enc_proj_bias; g.rowmask = attention_mask;
+            PTTS_TRY(launch_gemm(e, g, s));
+            enc_h = e->enc_h;
+        } else {   // no enc_to_dec_proj (M:2010-2014 is skipped), only the mask multiply
+            HIP_TRY(rowmask_mul_launch(enc_states, attention_mask, e->enc_h, M, D, s));
+            enc_h = e->enc_h;
+        }
+        // cross K/V of every layer into the cross pool (M:295-298)
+        for (int l = 0; l < c.layers; ++l) {
+            g = GemmArgs();
+            g.W = e->layers[l].ckv.ptr; g.N = 2 * D; g.K = D; g.M = M; g.pro = PRO_ROWMAJOR; g.x = enc_h; g.ldx = D;
+            g.epi = EPI_KV_CROSS; g.pool = make_pool(e, true); g.layer = l; g.D = D; g.T = T;
+            PTTS_TRY(launch_gemm(e, g, s));
+        }
     }
     // loop state
     StepState st = {};

@@ -460,7 +460,7 @@ class ParlerTTSForConditionalGeneration:
         stopping_criteria = list(stopping_criteria) if stopping_criteria else []
         allowed = {"input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "encoder_outputs",
                    "prompt_hidden_states", "decoder_input_ids", "return_raw_ids", "input_values", "padding_mask",
-                   "decoder_attention_mask"}
+                   "decoder_attention_mask", "_decoder_only"}
         unsupported = set()
         for k in model_kwargs:
             if k in unsupported:
@@ -472,19 +472,34 @@ class ParlerTTSForConditionalGeneration:
         # 3. inputs (M:2449-2452)
         input_ids = inputs if inputs is not None else model_kwargs.get("input_ids")
         enc_out = model_kwargs.get("encoder_outputs")
-        if input_ids is None and enc_out is None:
+        # decoder-only driver (ParlerTTSForCausalLM.generate, M:1281-1552): {"batch": B} - encoder states are optional there
+        # (no cross-attention block without them, M:465) and arrive ALREADY doubled under guidance (M:1218-1232 doubles only
+        # the decoder ids and the prompt; encoder_hidden_states go to the decoder as the caller passed them)
+        dec_only = model_kwargs.get("_decoder_only")
+        if input_ids is None and enc_out is None and dec_only is None:
             raise ValueError("generate() needs description `input_ids` (or `encoder_outputs`)")
         dev = self.device
-        if enc_out is not None:
+        enc = None
+        if dec_only is not None and enc_out is None:
+            B, T = int(dec_only["batch"]), 0
+        elif enc_out is not None:
             enc = enc_out[0] if isinstance(enc_out, (tuple, list)) else getattr(enc_out, "last_hidden_state", enc_out)
             enc = enc.to(dev, torch.float32)
             B, T = enc.shape[:2]
+            if dec_only is not None:
+                B = int(dec_only["batch"])
         else:
             input_ids = input_ids.to(dev)
             B, T = input_ids.shape
+        gs0 = gen.guidance_scale
+        enc_rows = B * (2 if (dec_only is not None and gs0 is not None and gs0 > 1) else 1)      # rows the caller must have passed
+        if enc is not None and enc.shape[0] != enc_rows:
+            raise ValueError(f"encoder hidden states must have {enc_rows} rows (batch {B}"
+                             + (", doubled by the caller under guidance_scale > 1: the decoder-only driver doubles only the "
+                                "decoder ids and the prompt, M:1218-1232" if enc_rows != B else "") + f"), got {enc.shape[0]}")
         attention_mask = model_kwargs.get("attention_mask")
         if attention_mask is None:    # M:2462-2465 (pad == eos, so HF does not infer a mask from pad tokens)
-            attention_mask = torch.ones(B, T, dtype=torch.long, device=dev)
+            attention_mask = torch.ones(enc_rows, T, dtype=torch.long, device=dev)
         attention_mask = attention_mask.to(dev)
         prompt_ids = model_kwargs.get("prompt_input_ids")
         prompt_mask = model_kwargs.get("prompt_attention_mask")
@@ -572,19 +587,19 @@ class ParlerTTSForConditionalGeneration:
             if t is not None and t.numel() and (int(t.min()) < 0 or int(t.max()) >= hi):
                 raise IndexError(f"index out of range in self: `{name}` must be in [0, {hi})")
 
-        if tuple(attention_mask.shape) != (B, T):
-            raise ValueError(f"attention_mask must be [batch {B}, description length {T}], got {tuple(attention_mask.shape)}")
+        if tuple(attention_mask.shape) != (enc_rows, T):
+            raise ValueError(f"attention_mask must be [batch {enc_rows}, description length {T}], got {tuple(attention_mask.shape)}")
         if prompt_ids is not None and (prompt_ids.dim() != 2 or prompt_ids.shape[0] != B):
             raise ValueError(f"prompt_input_ids must be [batch {B}, prompt_len], got {tuple(prompt_ids.shape)}")
         if prompt_mask is not None and tuple(prompt_mask.shape) != (B, P):
             raise ValueError(f"prompt_attention_mask must be [batch {B}, prompt length {P}], got {tuple(prompt_mask.shape)}")
-        if enc_out is not None and enc.shape[-1] != cfgm.text_encoder.d_model:
+        if enc_out is not None and enc is not None and enc.shape[-1] != cfgm.text_encoder.d_model:
             raise ValueError(f"encoder_outputs must be [batch, T, {cfgm.text_encoder.d_model}], got {tuple(enc.shape)}")
         if enc_out is None:
             _in_range("input_ids", input_ids, cfgm.text_encoder.vocab_size)
         _in_range("prompt_input_ids", prompt_ids, cfgm.vocab_size)
         _in_range("decoder_input_ids", ids, dec.vocab_size + 1)       # embed_tokens has vocab_size + 1 rows (M:769-773)
-        eng = self.engine(B_eff * nrs, T, P, L)
+        eng = self.engine(B_eff * nrs, max(T, 1), P, L)
         import time as _time
 
         def _tick():
@@ -594,17 +609,23 @@ class ParlerTTSForConditionalGeneration:
             return _time.perf_counter()
 
         t_start = _tick()
-        if enc_out is None:
+        if enc_out is None and dec_only is None:
             enc = eng.t5_encode(input_ids, attention_mask)                                   # M:2467-2474
+        if enc is None:                        # no encoder states: a placeholder row set the engine never reads (T = 0)
+            enc = torch.zeros(B_eff, 0, cfgm.text_encoder.d_model, device=dev)
         # classifier-free guidance: zeroed 'null' half (M:2231-2237), prompts repeated (M:2109-2118)
         amask32 = attention_mask.to(torch.int32)
-        if use_cfg:
+        if use_cfg and dec_only is None:
             enc = torch.cat([enc, torch.zeros_like(enc)], dim=0)
             amask32 = torch.cat([amask32, torch.zeros_like(amask32)], dim=0)
         pids = None if prompt_ids is None else prompt_ids.to(dev, torch.int64)
         pmask32 = None if prompt_mask is None else prompt_mask.to(dev, torch.int32)
         pemb = None if prompt_embeds is None else prompt_embeds.to(dev, torch.float32)
-        if use_cfg:
+        if use_cfg and dec_only is not None:
+            # decoder-only driver (M:1218-1232): the null half gets a ZEROED prompt and an all-zero prompt mask
+            pemb = None if pemb is None else torch.cat([pemb, torch.zeros_like(pemb)], dim=0)
+            pmask32 = None if pmask32 is None else torch.cat([pmask32, torch.zeros_like(pmask32)], dim=0)
+        elif use_cfg:
             pids = None if pids is None else pids.repeat(2, 1)
             pmask32 = None if pmask32 is None else pmask32.repeat(2, 1)
             pemb = None if pemb is None else pemb.repeat(2, 1, 1)                            # M:2115-2116
@@ -693,18 +714,26 @@ class ParlerTTSForConditionalGeneration:
                         L_out = st.cur_len
                         break
             remaining = 0
-        chunk = 1 if streamer is not None else 128
+        # a streamer is fed one column per decoding step (M:2540-2541 + the third-party loop), but the host only polls the
+        # device every `poll_steps` steps (streamer attribute, default 8): one state read-back and one copy per poll
+        chunk = max(1, int(getattr(streamer, "poll_steps", 8))) if streamer is not None else 128
+        fed = start_len                                   # columns already handed to the streamer
         while remaining > 0:
             n = min(chunk, remaining)
             eng.decode_steps(n, sp, self.profile_every)
             remaining -= n
             if streamer is not None:
                 st = eng.state()
-                streamer.put(raw_ids[:, st.cur_len - 1].cpu())
+                upto = st.done_len or st.cur_len
+                if upto > fed:
+                    cols = raw_ids[:, fed:upto].cpu()
+                    for c in range(cols.shape[1]):
+                        streamer.put(cols[:, c])
+                    fed = upto
                 if st.done_len:
                     L_out = st.done_len
                     break
-            elif gen.eos_token_id is not None and (remaining == 0 or self._may_finish_early()):
+            elif gen.eos_token_id is not None:
                 st = eng.state()
                 if st.done_len:
                     L_out = st.done_len
@@ -752,10 +781,6 @@ class ParlerTTSForConditionalGeneration:
             return ModelOutput(sequences=values)
         return values
 
-    def _may_finish_early(self) -> bool:
-        # with the synthetic never-EOS heads no row can finish; real checkpoints poll every chunk
-        return True
-
 
 class ParlerTTSForCausalLM:
     """Decoder-only driver with the reference's ``generate()`` contract (M:1281-1552): codec ids in, codec ids
@@ -768,8 +793,9 @@ class ParlerTTSForCausalLM:
     ``encoder_hidden_states`` here (M:1096-1185), the composite path multiplies by the mask (M:2016-2017); masked keys
     carry weight exactly 0 in cross-attention either way, so the ids are the same.
 
-    Not served (raise): ``guidance_scale > 1`` (the reference doubles only the prompt here, M:1218-1232, and leaves the
-    encoder states to the caller) and calls without ``encoder_hidden_states`` (the engine always cross-attends)."""
+    ``guidance_scale > 1``: as M:1218-1232, only the decoder ids and the prompt are doubled here (the null half gets a zeroed
+    prompt under an all-zero prompt mask); ``encoder_hidden_states`` / ``encoder_attention_mask`` must arrive with 2 x batch
+    rows.  Without ``encoder_hidden_states`` the layers run without their cross-attention block (M:465)."""
 
     config_class = ParlerTTSDecoderConfig
 
@@ -832,18 +858,24 @@ class ParlerTTSForCausalLM:
         ``[batch, P, hidden]`` + ``prompt_attention_mask``.  Returns the un-delayed ids ``[batch, num_codebooks, frames]``
         (M:1532-1546)."""
         kwargs = dict(kwargs)
-        gs = kwargs.get("guidance_scale", (generation_config or self.generation_config).guidance_scale)
-        if gs is not None and gs > 1:
-            raise NotImplementedError("guidance_scale > 1 on the decoder-only driver: the reference doubles only the prompt "
-                                      "(M:1218-1232); use ParlerTTSForConditionalGeneration for classifier-free guidance")
         enc = kwargs.pop("encoder_hidden_states", None)
-        if enc is None:
-            raise ValueError("ParlerTTSForCausalLM.generate needs `encoder_hidden_states` [batch, T, hidden]")
-        if enc.dim() != 3 or enc.shape[-1] != self.config.hidden_size:
+        if enc is not None and (enc.dim() != 3 or enc.shape[-1] != self.config.hidden_size):
             raise ValueError(f"encoder_hidden_states must be [batch, T, {self.config.hidden_size}], got {tuple(enc.shape)}")
         ids = inputs if inputs is not None else kwargs.pop("input_ids", None)
         kwargs.pop("input_ids", None)
-        inner = dict(encoder_outputs=(enc,), attention_mask=kwargs.pop("encoder_attention_mask", None), return_raw_ids=True)
+        prompt_h = kwargs.get("prompt_hidden_states")
+        if ids is not None:
+            batch = ids.shape[0] // self.num_codebooks
+        elif prompt_h is not None:
+            batch = prompt_h.shape[0]
+        elif enc is not None:
+            gs = kwargs.get("guidance_scale", (generation_config or self.generation_config).guidance_scale)
+            batch = enc.shape[0] // (2 if (gs is not None and gs > 1) else 1)
+        else:
+            batch = 1                                   # M:1441-1446: one BOS column
+        inner = dict(attention_mask=kwargs.pop("encoder_attention_mask", None), return_raw_ids=True, _decoder_only={"batch": batch})
+        if enc is not None:
+            inner["encoder_outputs"] = (enc,)
         if ids is not None:
             inner["decoder_input_ids"] = ids
         dmask = kwargs.pop("attention_mask", None)

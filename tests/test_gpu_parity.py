@@ -949,6 +949,44 @@ def test_streamer_protocol(hip):
     assert torch.equal(streamed, model.last_raw_ids.cpu()[:, 1:])
 
 
+def test_audio_streamer_chunks_add_up_to_the_one_shot_waveform(hip):
+    """Streaming with chunked DAC decode: AudioStreamer un-delays the id columns as they arrive and decodes
+    windows of play_frames + 2 x context frames; the codec decoder is a stack of finite convolutions, so with a context of
+    its receptive field the concatenated chunks equal the waveform generate() returns after the loop, sample for sample.
+    Also the polling: with poll_steps = 5 the host reads the device state every 5 steps, the streamer still sees every column
+    exactly once."""
+    from parler_tts_amd.configuration import tiny_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.streamer import AudioStreamer, dac_context_frames
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    assert dac_context_frames((8, 8, 4, 2)) == 10           # the 44 kHz DAC: 10 frames of context per side
+    cfg = tiny_config(max_positions=512)
+    sd = synthetic_state_dict(cfg, seed=11, never_eos=True, ln_jitter=0.1)
+    _models.clear()
+    torch.cuda.empty_cache()
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device="cuda:0")
+    g = torch.Generator().manual_seed(3)
+    desc = torch.randint(2, cfg.text_encoder.vocab_size, (2, 9), generator=g)
+    prompt = torch.randint(2, cfg.vocab_size, (2, 5), generator=g)
+    L = 160
+    kw = dict(input_ids=desc, prompt_input_ids=prompt, do_sample=False, max_length=L)
+    want = model.generate(**kw).cpu()
+    seen = []
+    st = AudioStreamer(model, play_frames=20, poll_steps=5, on_audio=lambda c, last: seen.append((c.shape[-1], last)))
+    got = model.generate(streamer=st, **kw).cpu()
+    assert torch.equal(got, want)
+    assert len(st.cols) == L and st.emitted == L - cfg.decoder.num_codebooks
+    wav = st.waveform()
+    assert wav.shape == want.shape and len(st.chunks) >= 5 and seen[-1][1] and not seen[0][1]
+    assert float((wav - want).abs().max()) < 1e-6, float((wav - want).abs().max())
+    assert sum(1 for _ in st) == len(st.chunks)             # the queue holds every chunk, then the end marker
+    with pytest.raises(ValueError):
+        AudioStreamer(model, context_frames=3)
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
     from parler_tts_amd.configuration import GenerationConfig
     from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
@@ -1571,12 +1609,23 @@ def test_decoder_only_driver(hip):
     K = cfg.decoder.num_codebooks
     again = model.generate(torch.full((3 * K, 1), cfg.decoder.bos_token_id), **kw)
     assert torch.equal(again, codes)
-    with pytest.raises(ValueError):
-        model.generate(do_sample=False, max_length=24)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):           # guidance: the caller must pass encoder states with 2 x batch rows (M:1218-1232)
         model.generate(guidance_scale=3.0, **kw)
     with pytest.raises(ValueError):
         model.generate(num_beams=2, **kw)
+    # guidance_scale > 1 and no encoder states at all: fixtures from the real class
+    for name in ("tiny_causal_cfg", "tiny_causal_noenc"):
+        g, gmeta = load_case(name)
+        u = lambda k: torch.from_numpy(g[k]) if k in g else None
+        kw2 = dict(prompt_hidden_states=u("prompt_h"), prompt_attention_mask=u("pmask"), do_sample=False, max_length=int(g["max_length"]))
+        if u("enc_h") is not None:
+            kw2.update(encoder_hidden_states=u("enc_h"), encoder_attention_mask=u("emask"))
+        if gmeta["guidance_scale"]:
+            kw2["guidance_scale"] = gmeta["guidance_scale"]
+        codes2 = model.generate(**kw2)
+        assert torch.equal(codes2.cpu(), u("codes")), name
+        free2 = torch.from_numpy(g["pattern"][:, 1:] == -1)
+        assert torch.equal(model.last_raw_ids.cpu()[:, 1:][free2], u("raw_ids")[:, 1:][free2]), name
 
 
 def test_lookahead_cross_q_two_m_tiles_bf16(hip):

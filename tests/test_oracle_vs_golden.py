@@ -136,6 +136,22 @@ def test_decoder_only_driver_matches_reference():
     assert float(f["free_min_margin"]) >= 1e-3
 
 
+@pytest.mark.parametrize("name", ["tiny_causal_cfg", "tiny_causal_noenc"])
+def test_decoder_only_driver_guidance_and_no_encoder_match_reference(name):
+    """The two call shapes of ParlerTTSForCausalLM.generate round 1 refused, on the real class: guidance_scale > 1 (the driver
+    doubles ids and prompt - zeroed prompt, zero prompt mask - and the caller the encoder states, M:1218-1232) and no
+    encoder_hidden_states (layers without their cross-attention block, M:465)."""
+    f, meta = load_case(name)
+    cfg, sd = state_dict_for(name, meta)
+    t = lambda k: torch.from_numpy(f[k]) if k in f else None
+    r = cpu_ref.generate_ids(cfg, sd, t("enc_h"), t("emask"), None, t("pmask"), int(f["max_length"]), record_logits=64,
+                             prompt_hidden_states=t("prompt_h"), decoder_only=True, guidance_scale=meta["guidance_scale"])
+    assert np.abs(r["step_logits"].numpy() - f["step_logits"]).max() < 2e-5
+    assert np.array_equal(r["raw_ids"].numpy(), f["raw_ids"])
+    assert np.array_equal(cpu_ref.undelay(cfg, r["raw_ids"], r["pattern"])[0].numpy(), f["codes"])
+    assert float(f["free_min_margin"]) >= 1e-3
+
+
 def test_static_kv_equals_cat_kv():
     f, meta = load_case("tiny_greedy")
     cfg, sd = state_dict_for("tiny_greedy", meta)
