@@ -77,7 +77,10 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     float q[EPL];
     const float* bias = a.bias ? a.bias + (size_t)bu * a.ld_bias : nullptr;
     // page ids once into LDS: KV addresses then depend on no global load
-    for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[bu * a.pool.max_blocks + i];
+    const bool ident = a.pool.block_table == nullptr;      // identity table: page of block i is bu * max_blocks + i
+    if (!ident)
+        for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[bu * a.pool.max_blocks + i];
+    const int page0 = bu * a.pool.max_blocks;
     const size_t page_elems = a.pool.page_elems();       // stride between two pages inside this head's K (or V) slab
     const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         const float* qp = a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) q[j] = qp[j];
-        __syncthreads();
+        if (!ident) __syncthreads();          // the page ids are in LDS
     }
     const int ntiles = (S + TPW - 1) / TPW;
 
@@ -124,7 +127,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         for (int u = 0; u < UNR; ++u) {
             int tok = (t0 + u * NWAVES) * TPW + tt;
             if (tok > S - 1) tok = S - 1;
-            const raw_t* src = reinterpret_cast<const raw_t*>(pool + (size_t)pages[tok >> 6] * page_elems + head_off + kv_add +
+            const int pg = ident ? page0 + (tok >> 6) : pages[tok >> 6];
+            const raw_t* src = reinterpret_cast<const raw_t*>(pool + (size_t)pg * page_elems + head_off + kv_add +
                                                               (size_t)(tok & 63) * PTTS_HEAD_DIM);
             // the cache is read exactly once per step: non-temporal loads keep 170 MB per launch from sweeping the L2s
             // (measured 34.4 -> 31.3 us per launch, decode pass -7 %)
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     const int S = a.len;
     const int tt = lane / LPT, c = lane % LPT;
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
-    const int page = a.pool.block_table[bu * a.pool.max_blocks];
+    const int page = a.pool.block_table ? a.pool.block_table[bu * a.pool.max_blocks] : bu * a.pool.max_blocks;
     const elem_t* kp = pool + (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() +
                        (size_t)page * a.pool.page_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
@@ -406,7 +410,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_causal_kernel(AttnArgs a, in
     const int row = b * a.npos + i;
     const int tt = lane / LPT, c = lane % LPT;
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
-    const int* table = a.pool.block_table + (size_t)b * a.pool.max_blocks;
+    const int* table = a.pool.block_table ? a.pool.block_table + (size_t)b * a.pool.max_blocks : nullptr;
+    const int page0 = b * a.pool.max_blocks;
     const size_t page_elems = a.pool.page_elems();
     const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
@@ -419,7 +424,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_causal_kernel(AttnArgs a, in
     }
     const int ntiles = (S + TPW - 1) / TPW;
     auto kv_ptr = [&](int tok, size_t add) {
-        return reinterpret_cast<const raw_t*>(pool + (size_t)table[tok >> 6] * page_elems + head_off + add +
+        const int pg = table ? table[tok >> 6] : page0 + (tok >> 6);
+        return reinterpret_cast<const raw_t*>(pool + (size_t)pg * page_elems + head_off + add +
                                               (size_t)(tok & 63) * PTTS_HEAD_DIM);
     };
     float m = -INFINITY;

@@ -132,6 +132,7 @@ struct ptts_engine {
     void *self_pool = nullptr, *cross_pool = nullptr;
     int *self_table = nullptr, *cross_table = nullptr;
     int self_blocks = 0, cross_blocks = 0, self_pages = 0;
+    bool self_identity = true;   // self_table still holds the identity page table
     // workspaces
     int mtiles = 1;
     float *x = nullptr, *q = nullptr, *logits = nullptr, *probs = nullptr, *enc_h = nullptr;
@@ -221,7 +222,8 @@ int dev_alloc(ptts_engine* e, void** p, size_t bytes) {
 KVPool make_pool(const ptts_engine* e, bool cross) {
     KVPool p;
     p.base = cross ? e->cross_pool : e->self_pool;
-    p.block_table = cross ? e->cross_table : e->self_table;
+    // NULL while the table is the identity (the default allocation; ptts_set_block_table installs a real one)
+    p.block_table = cross ? (const int*)nullptr : (e->self_identity ? (const int*)nullptr : e->self_table);
     p.max_blocks = cross ? e->cross_blocks : e->self_blocks;
     p.H = e->cfg.heads;
     p.L = e->cfg.layers;
@@ -783,6 +785,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     if (const char* v = getenv("PTTS_FOLD_MASK")) e->fold_mask = atoi(v);
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     e->seq_prefill = getenv("PTTS_PREFILL_SEQ") != nullptr && atoi(getenv("PTTS_PREFILL_SEQ")) != 0;
+    e->self_identity = getenv("PTTS_FORCE_PAGE_TABLE") == nullptr;     // A/B: always go through the table read
     if (const char* v = getenv("PTTS_PREFILL_CHUNK")) { e->pf_chunk = atoi(v); if (e->pf_chunk < 1) e->pf_chunk = 1; }
     if (cfg->dac_hidden > 0) {
         if (cfg->dac_n_up <= 0 || cfg->dac_n_up > 8 || cfg->dac_hidden % (16 << cfg->dac_n_up) != 0 || cfg->dac_latent % 16 != 0) {
@@ -1323,6 +1326,9 @@ int ptts_set_block_table(ptts_engine* e, const int32_t* table_host, int32_t rows
         seen[p] = 1;
     }
     HIP_TRY(hipMemcpy(e->self_table, table_host, sizeof(int) * rows * max_blocks, hipMemcpyHostToDevice));
+    e->self_identity = true;
+    for (int i = 0; i < rows * max_blocks; ++i) if (table_host[i] != i) { e->self_identity = false; break; }
+    if (getenv("PTTS_FORCE_PAGE_TABLE")) e->self_identity = false;
     e->prefilled = false;
     drop_graph(e);
     return PTTS_OK;

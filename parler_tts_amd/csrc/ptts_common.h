@@ -84,7 +84,9 @@ template <> __host__ __device__ inline size_t wpack_off<PF32>(int n, int k, int 
 // (measured: [page][L][2][H] 37.2 us per launch, [L][2][page][H] 34.0 us, this layout see DESIGN.md).
 struct KVPool {
     void* base;            // element type = cache dtype
-    const int* block_table;  // [B][max_blocks] page ids
+    const int* block_table;  // [B][max_blocks] page ids; NULL = the identity table (utterance b owns pages b*max_blocks ...):
+                             // the engine passes NULL while its table IS the identity, which takes the dependent table read
+                             // (and, in the decode kernel, the LDS hand-over behind it) out of every attention launch
     int max_blocks;
     int H;
     int L;
@@ -93,7 +95,7 @@ struct KVPool {
     __host__ __device__ size_t head_elems() const { return (size_t)n_pages * page_elems(); }             // one (layer, kv, head) slab
     __host__ __device__ size_t kv_elems() const { return (size_t)H * head_elems(); }                     // one (layer, kv) slab
     __device__ size_t elem_off(int b, int layer, int kv, int h, int tok) const {
-        int page = block_table[b * max_blocks + (tok >> 6)];
+        int page = block_table ? block_table[b * max_blocks + (tok >> 6)] : b * max_blocks + (tok >> 6);
         return ((size_t)((layer * 2 + kv) * H + h) * n_pages + page) * page_elems() + (size_t)(tok & 63) * PTTS_HEAD_DIM;
     }
 };

@@ -13,8 +13,9 @@ the pattern of row ``k`` is::
       k <= t < s + k      -> prompt[t-k]  (decoder prompt of length s, shifted right by k)
       otherwise           -> -1           (free: the model's prediction is kept)
 
-Written in closed form with index comparisons (no triangular matrices), so the same expression is
-what the HIP step kernel evaluates per (row, step) on device (csrc/select.hip: ``delay_forced``).
+Written in closed form with index comparisons (no triangular matrices).  The pattern matrix itself goes to the
+engine (``ptts_prefill``'s ``pattern`` argument): ``select_kernel`` (csrc/misc.hip) reads its column ``cur_len`` to feed
+the next step the forced value where it is not -1, which is ``apply_delay_pattern_mask`` on the last column.
 """
 from __future__ import annotations
 

@@ -689,29 +689,30 @@ class ParlerTTSForConditionalGeneration:
             # (processors on [B*K, vocab] scores after the guidance combine, then the warpers inside the select kernel)
             V = dec.vocab_size
             n = B_gen * K
+            cur = start_len                       # columns filled so far: known on the host (one column per step)
             while remaining > 0:
                 eng.forward_step()
-                st = eng.state()
-                scores = eng.last_logits(B_eff * K)
+                scores = eng.last_logits(B_eff * K)          # synchronises the stream; the only copy out per step
                 if use_cfg:
                     scores = scores[n:] + (scores[:n] - scores[n:]) * float(gen.guidance_scale)      # M:2556-2558
-                seen = raw_ids[:, :st.cur_len]
+                seen = raw_ids[:, :cur]
                 for proc in logits_processor:
                     scores = proc(seen, scores)
                 eng.set_logits(torch.cat([scores, scores], dim=0) if use_cfg else scores)
                 eng.select_step(sp)
                 remaining -= 1
-                st = eng.state()
+                cur += 1
+                st = eng.state()                               # one read-back per step: the EOS criterion is a host decision here
                 if streamer is not None:
-                    streamer.put(raw_ids[:, st.cur_len - 1].cpu())
+                    streamer.put(raw_ids[:, cur - 1].cpu())
                 if st.done_len:
                     L_out = st.done_len
                     break
                 if stopping_criteria:
-                    seen = raw_ids[:, :st.cur_len]
+                    seen = raw_ids[:, :cur]
                     stop = [c(seen, scores) for c in stopping_criteria]
                     if any(bool(torch.as_tensor(x).all()) for x in stop):
-                        L_out = st.cur_len
+                        L_out = cur
                         break
             remaining = 0
         # a streamer is fed one column per decoding step (M:2540-2541 + the third-party loop), but the host only polls the
