@@ -27,6 +27,7 @@
 // while they are staged (after Snake).  256 time rows x TN outputs per 8-wave workgroup, 32-channel chunks.
 #include "ptts_common.h"
 #include "conv.h"
+#include <cstdlib>
 
 namespace {
 
@@ -336,6 +337,144 @@ __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming 1x1 convolution of a residual unit (HF modeling_dac.py:175-210: x + conv1(snake(h))) for the narrow, long
+// blocks (C = 96 / 192 channels, T up to 1.3 M rows per utterance), where the layer is HBM-bound: 3 tensor passes (read h,
+// read x, write x') against 2 C^2 flops per row.  A 1x1 conv has no halo and no tap reuse, so staging the activations in
+// LDS (conv_kernel_h3: two barriers per 32-channel chunk, one workgroup per CU) only costs: here every wave streams its
+// own 16-row tiles straight from global memory into MFMA B fragments (lane = (channel group g, row t): 8 consecutive
+// channels = 32 contiguous bytes, the four groups of a row one 128-byte line), applies Snake and the fp16 hi / lo split
+// in registers, and multiplies with the weight fragments that sit in LDS for the whole launch (A-operand order, hi + lo:
+// 36 KB at C = 96, 144 KB at C = 192).  No barrier after the weights are parked; the epilogue adds bias and the residual
+// and stores 4 consecutive channels per lane.  Same products in the same order as conv_kernel_h3 (bl.xh, bh.xl, bh.xh per
+// 32-channel step, ascending): results are bit-identical to it.
+// ------------------------------------------------------------------------------------------------
+template <int C, int NWV>
+__global__ __launch_bounds__(NWV * 64) void conv1x1_stream_kernel(ConvArgs a, long long rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NB = C / 16, KS = C / 32;
+    half8* wh = reinterpret_cast<half8*>(smem);                  // [NB][KS][64 lanes]
+    half8* wl = wh + NB * KS * 64;
+    float* als = reinterpret_cast<float*>(wl + NB * KS * 64);    // [C] Snake alpha, [C] 1 / (alpha + 1e-9)
+    float* ivs = als + C;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, t16 = lane & 15;
+    {   // park the weights: tile (jb, m) lane l = W[16 jb + (l & 15)][32 m + 8 (l >> 4) .. + 7]
+        const _Float16* gh = reinterpret_cast<const _Float16*>(a.w_hi);
+        const _Float16* gl = reinterpret_cast<const _Float16*>(a.w_lo);
+        for (int i = tid; i < NB * KS * 64; i += NWV * 64) {
+            const int l = i & 63, m = (i >> 6) % KS, jb = (i >> 6) / KS;
+            const size_t off = (size_t)(16 * jb + (l & 15)) * C + 32 * m + 8 * (l >> 4);
+            wh[i] = *reinterpret_cast<const half8*>(gh + off);
+            wl[i] = *reinterpret_cast<const half8*>(gl + off);
+        }
+        for (int i = tid; i < C; i += NWV * 64) { const float al = a.alpha[i]; als[i] = al; ivs[i] = 1.0f / (al + 1e-9f); }
+    }
+    __syncthreads();
+    const long long ntiles = (rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * NWV + w; tile < ntiles; tile += (long long)gridDim.x * NWV) {
+        const long long row = tile * 16 + t16;
+        const bool live = row < rows;
+        const size_t rbase = (size_t)(live ? row : rows - 1) * C;
+        const float* xin = a.in + rbase + 8 * g;
+        f32x4 acc[NB];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) acc[jb] = {0, 0, 0, 0};
+        float4 v0 = *reinterpret_cast<const float4*>(xin), v1 = *reinterpret_cast<const float4*>(xin + 4);
+#pragma unroll
+        for (int m = 0; m < KS; ++m) {
+            const float4 c0 = v0, c1 = v1;
+            if (m + 1 < KS) {                      // next k-step's 32 bytes are requested before this step's matrix work
+                v0 = *reinterpret_cast<const float4*>(xin + 32 * (m + 1));
+                v1 = *reinterpret_cast<const float4*>(xin + 32 * (m + 1) + 4);
+            }
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(als + 32 * m + 8 * g), a1 = *reinterpret_cast<const f32x4*>(als + 32 * m + 8 * g + 4);
+            const f32x4 i0 = *reinterpret_cast<const f32x4*>(ivs + 32 * m + 8 * g), i1 = *reinterpret_cast<const f32x4*>(ivs + 32 * m + 8 * g + 4);
+            const float x8[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const float al8[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const float iv8[8] = {i0[0], i0[1], i0[2], i0[3], i1[0], i1[1], i1[2], i1[3]};
+            half8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = snake_f(x8[j], al8[j], iv8[j]);
+                _Float16 h, l;
+                split_h(y, h, l);
+                bh[j] = h;
+                bl[j] = l;
+            }
+            // C = 96: the 36 weight fragments are loop invariant and hipcc keeps them in registers (no LDS read per tile);
+            // C = 192 would need 576 registers for that: the clobber pins the reads inside the loop
+            if (C > 96) asm volatile("" ::: "memory");
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+                const half8 ah = wh[(jb * KS + m) * 64 + lane];
+                const half8 alo = wl[(jb * KS + m) * 64 + lane];
+                acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh, acc[jb], 0, 0, 0);
+                acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[jb], 0, 0, 0);
+                acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[jb], 0, 0, 0);
+            }
+        }
+        const float* resr = a.res + rbase + 4 * g;
+        float* outr = a.out + rbase + 4 * g;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            const float4 rv = *reinterpret_cast<const float4*>(resr + 16 * jb);
+            const float4 bs = *reinterpret_cast<const float4*>(a.bias + 16 * jb + 4 * g);
+            float4 y;
+            y.x = (acc[jb][0] + bs.x) + rv.x; y.y = (acc[jb][1] + bs.y) + rv.y;
+            y.z = (acc[jb][2] + bs.z) + rv.z; y.w = (acc[jb][3] + bs.w) + rv.w;
+            if (live) *reinterpret_cast<float4*>(outr + 16 * jb) = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Last layer of the codec decoder: snake -> Conv1d(C -> 1, k = 7) -> tanh (HF modeling_dac.py:436-442).  One output
+// channel makes it a memory-bound reduction (672 MACs per sample against 384 bytes read), not a GEMM: on the 64-wide MFMA
+// tiles of conv_kernel_h3 63 of 64 output columns are padding.  Here a thread owns one output sample; the input window
+// (256 + 6 rows, Snake applied once per element) goes through LDS in 32-channel chunks with a 33-float row stride
+// (consecutive threads read consecutive rows: conflict free), the 7 x C weights are wave-uniform scalar operands, the sum runs
+// in exact fp32 FMAs in (chunk, tap, channel) order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_last_kernel(ConvArgs a) {
+    constexpr int TR = 256, HALO = 6, CH = 32, LD = CH + 1;
+    __shared__ float xs[(TR + HALO) * LD];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * TR, b = blockIdx.y;
+    const float* inb = a.in + (size_t)b * (a.in_bs ? a.in_bs : (size_t)a.Tin * a.Cin);
+    float acc = 0.f;
+    for (int c0 = 0; c0 < a.Cin; c0 += CH) {
+        __syncthreads();
+        for (int i = tid; i < (TR + HALO) * (CH / 4); i += 256) {
+            const int r = i / (CH / 4), q = i % (CH / 4);
+            const int t = t0 - 3 + r;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (t >= 0 && t < a.Tin) {
+                v = *reinterpret_cast<const float4*>(inb + (size_t)t * a.Cin + c0 + 4 * q);
+                const float4 al = *reinterpret_cast<const float4*>(a.alpha + c0 + 4 * q);
+                v.x = snake_f(v.x, al.x, 1.0f / (al.x + 1e-9f)); v.y = snake_f(v.y, al.y, 1.0f / (al.y + 1e-9f));
+                v.z = snake_f(v.z, al.z, 1.0f / (al.z + 1e-9f)); v.w = snake_f(v.w, al.w, 1.0f / (al.w + 1e-9f));
+            }
+            float* d = xs + r * LD + 4 * q;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float* xr = xs + (tid + k) * LD;
+            const float* wk = a.w + (size_t)k * a.Cin + c0;       // packed [tap][N = 1][Cin]: uniform -> scalar loads
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc = fmaf(wk[c], xr[c], acc);
+        }
+    }
+    const int t = t0 + tid;
+    if (t < a.Tout) {
+        float y = acc + a.bias[0];
+        if (a.act_out == 1) y = tanhf(y);
+        a.out[(size_t)b * (a.out_bs ? a.out_bs : (size_t)a.Tout) + t] = y;
+    }
+}
+
 __global__ void split_halves_kernel(const float* src, _Float16* hi, _Float16* lo, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -507,7 +646,13 @@ hipError_t conv_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_stream_kernel<192, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_stream_kernel<192, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024);
 }
 
 size_t conv_h3_lds(const ConvArgs& a, int TN) {
@@ -519,6 +664,34 @@ size_t conv_h3_lds(const ConvArgs& a, int TN) {
 
 hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     if (a.taps > MAX_TAPS || a.Cin % KC != 0) return hipErrorInvalidValue;
+    // last layer (one output channel, 7 taps): the reduction kernel
+    if (getenv("PTTS_DAC_NO_LAST_KERNEL") == nullptr && a.Cout == 1 && a.N == 1 && a.taps == 7 && a.tstep == 1 && a.toff == -3 &&
+        a.stride == 1 && a.Cin % 32 == 0 && a.alpha && !a.res && a.Tin == a.Tout) {
+        hipLaunchKernelGGL(conv_last_kernel, dim3((a.Tout + 255) / 256, a.B), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    // residual 1x1 conv of the narrow, long blocks: the streaming kernel (dense rows, Snake on the input, residual add)
+    const bool no_stream = getenv("PTTS_DAC_NO_STREAM_1X1") != nullptr;      // A/B and the equivalence test
+    if (!no_stream && a.taps == 1 && a.stride == 1 && a.w_hi && a.w_lo && a.alpha && a.res && a.act_out == 0 && a.Cin == a.Cout &&
+        a.N == a.Cout && a.in_bs == 0 && a.out_bs == 0 && a.Tin == a.Tout && a.U == a.Tout && (a.Cin == 96 || a.Cin == 192)) {
+        const long long rows = (long long)a.B * a.Tout;
+        const long long tiles = (rows + 15) / 16;
+        if (a.Cin == 96) {
+            const size_t lds = (size_t)6 * 3 * 64 * 16 * 2 + 2 * 96 * sizeof(float);
+            long long g = (tiles + 3) / 4; if (g > 256 * 4) g = 256 * 4;
+            hipLaunchKernelGGL((conv1x1_stream_kernel<96, 4>), dim3((unsigned)g), dim3(256), lds, s, a, rows);
+        } else {
+            const size_t lds = (size_t)12 * 6 * 64 * 16 * 2 + 2 * 192 * sizeof(float);
+            if (getenv("PTTS_DAC_1X1_WAVES8")) {
+                long long g = (tiles + 7) / 8; if (g > 256) g = 256;
+                hipLaunchKernelGGL((conv1x1_stream_kernel<192, 8>), dim3((unsigned)g), dim3(512), lds, s, a, rows);
+            } else {
+                long long g = (tiles + 15) / 16; if (g > 256) g = 256;
+                hipLaunchKernelGGL((conv1x1_stream_kernel<192, 16>), dim3((unsigned)g), dim3(1024), lds, s, a, rows);
+            }
+        }
+        return hipGetLastError();
+    }
     if (a.w_hi && a.w_lo && a.Cin % KC3 == 0) {
         // TN = 96 when it divides N and fits LDS, else 64
         int TN = (a.N % 96 == 0 && conv_h3_lds(a, 96) <= 160 * 1024) ? 96 : 64;

@@ -674,6 +674,34 @@ def test_dac_decode_kernels(hip, name):
         dac.decode(bad[None], [None])
 
 
+def test_dac_streaming_1x1_conv_equals_the_tiled_kernel(hip):
+    """The residual 1x1 convs of the narrow blocks (C = 96 / 192) run on a streaming kernel (activations straight from global
+    memory into MFMA B fragments, weights parked in LDS / registers); same products in the same order as the tiled kernel, so
+    the waveform must be bit-identical to the one computed with PTTS_DAC_NO_STREAM_1X1=1 (mini codec, 2 x 40 frames)."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
+    dac = DACModel(cfg, sd, device="cuda:0")
+    codes = torch.randint(0, 1024, (1, 2, 9, 40), generator=torch.Generator().manual_seed(1))
+    a = dac.decode(codes, None).audio_values.cpu()
+    for var in ("PTTS_DAC_NO_STREAM_1X1", "PTTS_DAC_1X1_WAVES8"):
+        os.environ[var] = "1"
+        try:
+            b = dac.decode(codes, None).audio_values.cpu()
+        finally:
+            del os.environ[var]
+        assert torch.equal(a, b), (var, float((a - b).abs().max()))
+    # the last layer (96 -> 1 channel) as an fp32 reduction kernel vs the MFMA tile kernel with the fp16 x 3 split
+    os.environ["PTTS_DAC_NO_LAST_KERNEL"] = "1"
+    try:
+        c = dac.decode(codes, None).audio_values.cpu()
+    finally:
+        del os.environ["PTTS_DAC_NO_LAST_KERNEL"]
+    assert float((a - c).abs().max()) < 5e-6 and float(a.abs().max()) > 0.05
+
+
 def test_dac_decode_long_clip_chunked_equals_unchunked(hip):
     """time tiles, halos across tile seams and batch chunks: a long clip decoded alone must equal the same
     clip decoded inside a batch (size-independent property used at the BASELINE sizes)."""

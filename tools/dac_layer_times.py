@@ -7,7 +7,7 @@ import glob
 import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "conv_kernel" in r["Kernel_Name"] or "dac_" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "conv" in r["Kernel_Name"] or "dac_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = len(rows) // 2                     # two decodes (warm-up + timed): keep the second
 rows = rows[n:]
@@ -15,6 +15,6 @@ tot = 0
 for i, r in enumerate(rows):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     tot += d
-    name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "")
+    name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
     print(f"{i:3d} {name:28s} grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>9s} {d:8.3f} ms")
 print(f"total {tot:.1f} ms over {len(rows)} launches")
