@@ -90,6 +90,24 @@ template <> struct Tile<PF32> {
     }
 };
 
+// four consecutive features n .. n+3 (n % 4 == 0) of one row in the fragment image: in the bf16 layout they are 8 contiguous
+// bytes (k & 7 runs over a 4-aligned quad), so ONE 8-byte store replaces four 2-byte stores; the fp32 layout interleaves
+// k & 3 across 16-lane groups (64 elements apart)
+template <typename P>
+__device__ inline void store_frag4(typename P::elem_t* of, int r32, int n, const float (&y)[4]);
+template <>
+__device__ inline void store_frag4<PBF16>(uint16_t* of, int r32, int n, const float (&y)[4]) {
+    uint2 pk;
+    pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{y[0], y[1]}, bf16x2));
+    pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{y[2], y[3]}, bf16x2));
+    *reinterpret_cast<uint2*>(of + frag_off<PBF16>(r32, n)) = pk;
+}
+template <>
+__device__ inline void store_frag4<PF32>(float* of, int r32, int n, const float (&y)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) of[frag_off<PF32>(r32, n + r)] = y[r];
+}
+
 template <typename P>
 __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x4 v1, const float4& xres, bool have_res) {
     // row: absolute output row; n: first of this lane's 4 consecutive output features
@@ -117,8 +135,7 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
             if (a.xfrag_out) {   // the next LayerNorm-folded projection reads the raw rows as B fragments
                 elem_t* of = reinterpret_cast<elem_t*>(a.xfrag_out) + (size_t)(row >> 5) * 32 * a.ldo;
                 const float xv[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) of[frag_off<P>(row & 31, n + r)] = to_elem<P>(xv[r]);
+                store_frag4<P>(of, row & 31, n, xv);
             }
             break;
         }
@@ -130,12 +147,14 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
         case EPI_ACT_FRAG:
         case EPI_GATED_FRAG: {
             elem_t* of = reinterpret_cast<elem_t*>(a.ofrag) + (size_t)(row >> 5) * 32 * a.ldo;
+            float yv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float y = act_apply(a.act, v[r]);
                 if (a.epi == EPI_GATED_FRAG) y *= v1[r];
-                of[frag_off<P>(row & 31, n + r)] = to_elem<P>(y);
+                yv[r] = y;
             }
+            store_frag4<P>(of, row & 31, n, yv);
             break;
         }
         case EPI_QKV_SELF:
