@@ -8,6 +8,8 @@ struct ConvArgs {
     const float* w = nullptr;      // packed [taps][N][Cin]
     const void* w_hi = nullptr;    // the same weights split into fp16 hi / lo halves (fast path), or null
     const void* w_lo = nullptr;
+    const void* w_units = nullptr; // the split weights as LDS-DMA units [N / unit_tn][Cin / 32][taps][hi | lo][unit_tn][32] (conv_units_launch), or null
+    int unit_tn = 0;
     const float* bias = nullptr;   // [Cout]
     const float* alpha = nullptr;  // [Cin] Snake on the input, or null
     const float* res = nullptr;    // residual, same shape as out, or null (may alias out)
@@ -26,6 +28,9 @@ hipError_t dac_latent_launch(const long long* codes, const float* table, float* 
                              hipStream_t s);
 hipError_t dac_table_launch(const float* codebook, const float* proj_w, const float* proj_b, float* table, int ncodes, int dim,
                             int C, hipStream_t s);
+// same bytes as w_hi + w_lo, regrouped so that one tap of one 32-channel chunk of one TN-wide output block is contiguous and
+// already in the swizzled order the kernel reads from LDS
+hipError_t conv_units_launch(const void* hi, const void* lo, void* out, int taps, int N, int Cin, int TN, hipStream_t s);
 hipError_t split_halves_launch(const float* src, void* hi, void* lo, size_t n, hipStream_t s);
 hipError_t conv_pack_launch(const float* w, float* out, int Cout, int Cin, int k, int transposed, int stride, int N,
                             hipStream_t s);

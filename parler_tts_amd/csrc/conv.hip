@@ -27,7 +27,9 @@
 // while they are staged (after Snake).  256 time rows x TN outputs per 8-wave workgroup, 32-channel chunks.
 #include "ptts_common.h"
 #include "conv.h"
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -155,8 +157,17 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-constexpr int TM3 = 256;      // time rows per workgroup (8 waves x 32)
+#ifdef PTTS_CONV_STAMPS
+// diagnostic build (make CXXFLAGS+=-DPTTS_CONV_STAMPS): wave 0 of every workgroup adds the cycles of each phase of the chunk loop
+// [0] fetch issue  [1] MFMA loop  [2] barrier after it  [3] stash  [4] barrier before the next chunk  [5] chunks  [6] whole kernel
+__device__ unsigned long long g_conv_stamps[16];
+#define STAMP(i, t0) do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tacc[i] += t1_ - t0; t0 = t1_; } while (0)
+#else
+#define STAMP(i, t0) do { } while (0)
+#endif
 constexpr int KC3 = 32;       // channels per chunk = one fp16 MFMA k-step
+constexpr int h3_xa(int RW) { return RW == 32 ? 6 : 9; }                       // window float4 per thread the register staging holds
+constexpr int h3_max_span(int RW) { return h3_xa(RW) * 512 / (KC3 / 4) - 8 * RW; } // largest (taps - 1) * |tstep|: 128 | 64
 constexpr int LDH = KC3;      // row stride in halves: 64-byte rows, NO padding; conflicts are removed by an XOR swizzle instead
 // ds_read_b128 is served in four 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... MI355X_MICROARCH.md, LDS) over 64
 // banks of 4 B: with a fragment read of 16 rows x 4 columns of 16 B, an 80-byte padded stride puts two lanes of EVERY group on
@@ -169,25 +180,28 @@ __device__ inline void split_h(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
-template <int TN>
+// RW = time rows per wave (32 | 64): with 64 a wave reads 8 activation + 2 NT weight fragments per tap for 12 NT MFMAs instead
+// of 4 + 2 NT for 6 NT (the MFMA loop runs the LDS pipe at ~87 % of the matrix pipe's time with RW = 32), and a staged
+// chunk feeds twice the rows
+template <int TN, int RW>
 __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = TN / 16;
+    constexpr int NT = TN / 16, NI = RW / 16, TMW = 8 * RW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n0 = blockIdx.x * TN;
-    const int u0 = blockIdx.y * TM3;
+    const int u0 = blockIdx.y * TMW;
     const int b = blockIdx.z;
     const int lo_r = a.tstep >= 0 ? a.toff : a.toff + (a.taps - 1) * a.tstep;
     const int hi_r = a.tstep >= 0 ? a.toff + (a.taps - 1) * a.tstep : a.toff;
-    const int win = TM3 + (hi_r - lo_r);
+    const int win = TMW + (hi_r - lo_r);
     _Float16* xh = reinterpret_cast<_Float16*>(smem);            // [win][LDH] hi
     _Float16* xl = xh + (size_t)win * LDH;                       // [win][LDH] lo
     _Float16* wh = xl + (size_t)win * LDH;                       // [taps][TN][LDH] hi
     _Float16* wl = wh + (size_t)a.taps * TN * LDH;               // [taps][TN][LDH] lo
 
-    f32x4 acc[2][NT];
+    f32x4 acc[NI][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = {0, 0, 0, 0};
 
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
     // so global/L2 latency hides under the matrix work instead of sitting between two barriers (the kernel
     // holds one workgroup per CU: nothing else would cover it).  Measured on the 384-channel 7-tap layers:
     // MFMA time was ~1/3 of the single-buffered kernel.
-    constexpr int XA = 6;                                             // window float4 per thread (win <= 384)
+    constexpr int XA = h3_xa(RW);                                     // window float4 per thread (win <= TMW + h3_max_span(RW))
     constexpr int WR = (MAX_TAPS * TN * (KC3 / 8) + 511) / 512;       // weight uint4 pairs per thread
     const int nx = win * (KC3 / 4), nw = a.taps * TN * (KC3 / 8);
     float4 xr[XA];
@@ -265,46 +279,67 @@ __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
         }
     };
 
+#ifdef PTTS_CONV_STAMPS
+    unsigned long long ts = __builtin_amdgcn_s_memtime();
+    const unsigned long long ts_begin = ts;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
     fetch(0);
     stash();
     for (int c0 = 0; c0 < a.Cin; c0 += KC3) {
         __syncthreads();                                  // chunk c0 is in LDS
+        STAMP(4, ts);
         const bool more = c0 + KC3 < a.Cin;
         if (more) fetch(c0 + KC3);
         asm volatile("" ::: "memory");                    // keep the fetch above the MFMA loop (hipcc sinks loads to their use)
+        STAMP(0, ts);
         for (int tap = 0; tap < a.taps; ++tap) {
             const int roff = tap * a.tstep + a.toff - lo_r;
-            const int xrow = w * 32 + roff + (lane & 15);
+            const int xrow = w * RW + roff + (lane & 15);
             const size_t xo = (size_t)xrow * LDH + 8 * swz16(xrow, lane >> 4);     // row + 16 has the same bit 2
-            const half8 x0h = *reinterpret_cast<const half8*>(xh + xo);
-            const half8 x0l = *reinterpret_cast<const half8*>(xl + xo);
-            const half8 x1h = *reinterpret_cast<const half8*>(xh + xo + 16 * LDH);
-            const half8 x1l = *reinterpret_cast<const half8*>(xl + xo + 16 * LDH);
+            half8 xfh[NI], xfl[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                xfh[i] = *reinterpret_cast<const half8*>(xh + xo + (size_t)i * 16 * LDH);
+                xfl[i] = *reinterpret_cast<const half8*>(xl + xo + (size_t)i * 16 * LDH);
+            }
             const size_t wo = ((size_t)tap * TN + (lane & 15)) * LDH + 8 * swz16(lane & 15, lane >> 4);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const half8 bh = *reinterpret_cast<const half8*>(wh + wo + (size_t)j * 16 * LDH);
                 const half8 bl = *reinterpret_cast<const half8*>(wl + wo + (size_t)j * 16 * LDH);
                 // small terms first, then the leading term
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, x0h, acc[0][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x0l, acc[0][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x0h, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, x1h, acc[1][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x1l, acc[1][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, x1h, acc[1][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, xfh[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, xfl[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, xfh[i], acc[i][j], 0, 0, 0);
+                }
             }
         }
+        STAMP(1, ts);
         __syncthreads();                                  // every wave is done reading chunk c0
+        STAMP(2, ts);
         if (more) stash();
+        STAMP(3, ts);
+#ifdef PTTS_CONV_STAMPS
+        tacc[5] += 1;
+#endif
     }
+#ifdef PTTS_CONV_STAMPS
+    if (tid == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_stamps[i], tacc[i]);
+        atomicAdd(&g_conv_stamps[6], __builtin_amdgcn_s_memtime() - ts_begin);
+    }
+#endif
 
     // ---- epilogue (same as the fp32 kernel) ----
     const size_t obs = a.out_bs ? a.out_bs : (size_t)a.Tout * a.Cout;
     float* outb = a.out + (size_t)b * obs;
     const float* resb = a.res ? a.res + (size_t)b * obs : nullptr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = u0 + w * 32 + i * 16 + (lane & 15);
+    for (int i = 0; i < NI; ++i) {
+        const int u = u0 + w * RW + i * 16 + (lane & 15);
         if (u >= a.U) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -335,6 +370,282 @@ __global__ __launch_bounds__(512) void conv_kernel_h3(ConvArgs a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_kernel_h3r: the same arithmetic as conv_kernel_h3 (same products, same order: bit-identical results) with the weights
+// streamed by LDS-DMA instead of through registers.
+//
+// What bounded conv_kernel_h3 (in-kernel s_memtime stamps of a 768-channel 7-tap layer, cycles per 32-channel chunk of wave 0:
+// issuing the 18 staging loads 2.8 k, MFMA loop 7.3 k + 3.5 k at the barrier behind it for the slower waves, Snake / split /
+// ds_write 2.1 k, barrier 1.5 k; the matrix pipe has 8.1 k of work in those 17.2 k): (i) the 86 KB of tap weights go through 48
+// staging registers per lane, which is what keeps a wave at 32 rows: with 64 rows a wave reads 8 + 12 fragments per tap for 72
+// MFMAs instead of 4 + 12 for 36 (the MFMA loop holds the LDS pipe at 87 % of the matrix pipe's time at 32 rows), and a staged
+// window feeds twice the rows; (ii) all the loads of a chunk are issued in one burst the texture addresser takes 2.3 k cycles
+// to accept.  Here the weights of ONE tap of one chunk are a 12 KB unit (hi + lo image of TN x 32 halves, stored in exactly
+// the swizzled LDS order in global memory, so the copy is linear: two 12-byte global_load_lds per lane at TN = 96), units
+// travel through a ring of RS slots, D = RS - 1 units ahead of the MFMAs, and the activation loads of the next chunk are
+// spread over the taps.  Per unit: wait for the own DMA pieces of unit u (counted vmcnt: younger pieces stay in flight) ->
+// barrier (everyone's pieces of u are in LDS, everyone is done reading u - 1) -> issue the DMA of unit u + D into the slot of
+// u - 1 -> this tap's share of the activation loads -> fragments + MFMAs.  The activation window keeps its register staging
+// (Snake and the fp16 split need the VALU anyway) with one barrier on each side of the stash, as before.
+//
+// vmcnt bookkeeping (loads, LDS-DMA count together, in issue order): every step issues the same instructions on every wave -
+// the DMA of a unit past the end re-fetches the last unit into a free slot, activation loads are never branched around (out of
+// range lanes read row 0 and are zeroed in the stash) - so the number of operations younger than unit u's pieces at the wait is
+// a compile-time function of the tap (tables n_steady / n_last below; the first D units wait for everything but the pieces).
+// ------------------------------------------------------------------------------------------------
+template <int T, int TEND, class F> __device__ inline void static_for(F&& f) {
+    if constexpr (T < TEND) { f(std::integral_constant<int, T>{}); static_for<T + 1, TEND>(f); }
+}
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ inline void lds_barrier() {      // own LDS writes done, then the workgroup barrier; does NOT drain vmcnt (pending LDS-DMA)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int TN, int RW, int TAPS, int RS>
+struct H3R {
+    static constexpr int NT = TN / 16, NI = RW / 16, TMW = 8 * RW, D = RS - 1;
+    static constexpr int UB = TN * 128;                    // bytes of one weight unit
+    static constexpr int GS = 16;                          // bytes per lane and LDS-DMA instruction (12-byte pieces do not land lane x 12 apart)
+    static constexpr int PI = UB / (64 * GS);              // 1 KB wave-instructions a unit needs: 8 | 12 | 16
+    static constexpr int G = (PI + 7) / 8;                 // issued per wave and unit - the SAME on every wave (the vmcnt tables need that,
+                                                           // and a branch around a DMA makes hipcc drain vmcnt at the next load): at TN = 96
+                                                           // waves 4 .. 7 have no second piece and copy their first one again
+    static constexpr int XA = h3_xa(RW);
+    static constexpr int xs(int t) {                       // activation loads issued at tap t (+ the alpha row at tap 0)
+        int n = t == 0 ? 1 : 0;
+        for (int k = 0; k < XA; ++k) n += (k % TAPS == t) ? 1 : 0;
+        return n;
+    }
+    static constexpr int xrel(int j, bool more) {          // step j relative to this chunk's tap 0; j < 0: an earlier chunk
+        return j >= 0 ? (more ? xs(j % TAPS) : 0) : xs(((j % TAPS) + TAPS) % TAPS);
+    }
+    static constexpr int younger(int t, bool more) {       // operations issued after unit u's pieces, before its wait (u >= D)
+        int n = xrel(t - D, more);
+        for (int j = t - D + 1; j < t; ++j) n += G + xrel(j, more);
+        return n;
+    }
+    static constexpr int n_min = G * (D - 1);              // only the DMA pieces of the units in between: always a lower bound
+};
+
+template <int TN, int RW, int TAPS, int RS>
+__global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
+    using K = H3R<TN, RW, TAPS, RS>;
+    constexpr int NT = K::NT, NI = K::NI, TMW = K::TMW, D = K::D, UB = K::UB, GS = K::GS, XA = K::XA;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * TN;
+    const int u0 = blockIdx.y * TMW;
+    const int b = blockIdx.z;
+    const int lo_r = a.tstep >= 0 ? a.toff : a.toff + (TAPS - 1) * a.tstep;
+    const int hi_r = a.tstep >= 0 ? a.toff + (TAPS - 1) * a.tstep : a.toff;
+    const int win = TMW + (hi_r - lo_r);
+    char* ring = smem;                                           // [RS][hi: TN x 64 B | lo: TN x 64 B]; first: LDS-DMA bases stay below 64 KB
+    _Float16* xh = reinterpret_cast<_Float16*>(smem + RS * UB);  // [win][LDH] hi
+    _Float16* xl = xh + (size_t)win * LDH;                       // [win][LDH] lo
+
+    f32x4 acc[NI][NT];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = {0, 0, 0, 0};
+
+    const float* inb = a.in + (size_t)b * (a.in_bs ? a.in_bs : (size_t)a.Tin * a.Cin);
+    const int nchunks = a.Cin / KC3, nunits = nchunks * TAPS;
+    const char* units = reinterpret_cast<const char*>(a.w_units) + (size_t)blockIdx.x * nunits * UB;   // [chunk][tap] of this block
+    const bool snake = a.alpha != nullptr;
+    const float* alpha_src = snake ? a.alpha + 4 * (tid % (KC3 / 4)) : reinterpret_cast<const float*>(a.w_units);
+
+    // activation staging: the lane's piece k sits 64 rows below piece k - 1; lanes outside the window / the utterance read row 0
+    const int nx = win * (KC3 / 4);
+    float4 xr[XA];
+    float4 alr = make_float4(0, 0, 0, 0);
+    const int xq = tid % (KC3 / 4), xrow0 = tid / (KC3 / 4);
+    const unsigned xbase = (unsigned)(u0 + lo_r + xrow0) * (unsigned)a.Cin + 4 * xq;     // wraps for rows < 0: masked by xvalid
+    const unsigned xstep = 64u * (unsigned)a.Cin;
+    unsigned xvalid = 0;
+#pragma unroll
+    for (int k = 0; k < XA; ++k) {
+        const int t = u0 + lo_r + xrow0 + 64 * k;
+        xvalid |= (tid + 512 * k < nx && t >= 0 && t < a.Tin) ? 1u << k : 0u;
+    }
+    auto xload = [&](int k, int c0) {
+        const unsigned off = (xvalid >> k) & 1 ? xbase + k * xstep : 0u;
+        xr[k] = *reinterpret_cast<const float4*>(inb + off + c0);
+    };
+    auto aload = [&](int c0) { alr = *reinterpret_cast<const float4*>(alpha_src + (snake ? c0 : 0)); };
+    auto stash = [&]() {
+        const float4 inv = make_float4(1.0f / (alr.x + 1e-9f), 1.0f / (alr.y + 1e-9f), 1.0f / (alr.z + 1e-9f), 1.0f / (alr.w + 1e-9f));
+#pragma unroll
+        for (int k = 0; k < XA; ++k) {
+            if (tid + 512 * k < nx) {
+                const int r = xrow0 + 64 * k;
+                float4 v = (xvalid >> k) & 1 ? xr[k] : make_float4(0, 0, 0, 0);
+                if (snake) {   // Snake(0) = 0, so the zero padding needs no special case
+                    v.x = snake_f(v.x, alr.x, inv.x); v.y = snake_f(v.y, alr.y, inv.y);
+                    v.z = snake_f(v.z, alr.z, inv.z); v.w = snake_f(v.w, alr.w, inv.w);
+                }
+                _Float16 h[4], l[4];
+                split_h(v.x, h[0], l[0]); split_h(v.y, h[1], l[1]); split_h(v.z, h[2], l[2]); split_h(v.w, h[3], l[3]);
+                const int xo = r * LDH + 8 * swz16(r, xq >> 1) + 4 * (xq & 1);
+                *reinterpret_cast<uint2*>(xh + xo) = *reinterpret_cast<uint2*>(h);
+                *reinterpret_cast<uint2*>(xl + xo) = *reinterpret_cast<uint2*>(l);
+            }
+        }
+    };
+    // LDS-DMA of unit u into ring slot `slot`: wave-instruction m copies pieces 64 m .. 64 m + 63 (16 B each) of the linear image;
+    // wave w issues m = w, w + 8, .. (m = w again where the unit has no such piece)
+    auto dma = [&](int u, int slot) {
+        const int uc = u < nunits ? u : nunits - 1;
+        const char* src = units + (size_t)uc * UB + (size_t)tid * GS;
+        char* dst = ring + slot * UB + w * (64 * GS);
+#if defined(PTTS_RING_DEBUG_COPY)         // diagnostic build: the same pieces moved through registers (tells a layout bug from a DMA one)
+#pragma unroll
+        for (int j = 0; j < K::G; ++j) {
+            const int o = w + 8 * j < K::PI ? j * 512 * GS : 0;
+            *reinterpret_cast<uint4*>(dst + o + lane * GS) = *reinterpret_cast<const uint4*>(src + o);
+        }
+#elif defined(__HIP_DEVICE_COMPILE__)      // the builtin does not exist in the host pass, which would then drop the kernel's launch stub
+        typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+        for (int j = 0; j < K::G; ++j) {
+            const int o = w + 8 * j < K::PI ? j * 512 * GS : 0;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src + o), (lds_void*)(dst + o), 16, 0, 0);
+        }
+#else
+        (void)src; (void)dst;
+#endif
+    };
+
+#pragma unroll
+    for (int k = 0; k < XA; ++k) xload(k, 0);
+    aload(0);
+    stash();
+#pragma unroll
+    for (int v = 0; v < D; ++v) dma(v, v);
+
+#ifdef PTTS_CONV_STAMPS
+    unsigned long long ts = __builtin_amdgcn_s_memtime();
+    const unsigned long long ts_begin = ts;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};       // [0] DMA wait [1] tap barrier [2] issue [3] MFMA [4] chunk barrier [5] stash
+    unsigned long long nchunk_done = 0;
+#endif
+    int slot = 0;                                         // ring slot of the unit about to be consumed
+    // one chunk: MORE = the next chunk exists (its activation loads ride on the taps); the last chunk is peeled so that the loop
+    // body has no conditional loads (hipcc would otherwise merge "loads may be pending" into the loop head and drain vmcnt)
+    auto chunk = [&](int c, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
+        const int cn = (c + 1) * KC3;
+        static_for<0, TAPS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            // ---- unit u = c * TAPS + t: its pieces have landed (own wait, then everyone's through the barrier) ----
+            if (c * TAPS + t < D) wait_vmcnt<K::n_min>();
+            else wait_vmcnt<K::younger(t, more)>();
+            STAMP(0, ts);
+            lds_barrier();                                // at t = 0 also: the stashed window of chunk c is visible
+            STAMP(1, ts);
+            {
+                int ps = slot + D; if (ps >= RS) ps -= RS;
+                dma(c * TAPS + t + D, ps);                // into the slot unit u - 1 was read from
+            }
+            if constexpr (more) {
+#pragma unroll
+                for (int k = 0; k < XA; ++k) if (k % TAPS == t) xload(k, cn);
+                if (t == 0) aload(cn);
+            }
+            asm volatile("" ::: "memory");                // keep the loads above the MFMAs (hipcc sinks loads to their use)
+            STAMP(2, ts);
+            const _Float16* wh = reinterpret_cast<const _Float16*>(ring + slot * UB);
+            const _Float16* wl = wh + TN * LDH;
+            const int roff = t * a.tstep + a.toff - lo_r;
+            const int xrow = w * RW + roff + (lane & 15);
+            const size_t xo = (size_t)xrow * LDH + 8 * swz16(xrow, lane >> 4);     // row + 16 has the same bit 2
+            half8 xfh[NI], xfl[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                xfh[i] = *reinterpret_cast<const half8*>(xh + xo + (size_t)i * 16 * LDH);
+                xfl[i] = *reinterpret_cast<const half8*>(xl + xo + (size_t)i * 16 * LDH);
+            }
+            const size_t wo = (size_t)(lane & 15) * LDH + 8 * swz16(lane & 15, lane >> 4);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const half8 bh = *reinterpret_cast<const half8*>(wh + wo + (size_t)j * 16 * LDH);
+                const half8 bl = *reinterpret_cast<const half8*>(wl + wo + (size_t)j * 16 * LDH);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {            // small terms first, then the leading term
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, xfh[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, xfl[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, xfh[i], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (++slot == RS) slot = 0;
+            STAMP(3, ts);
+        });
+        lds_barrier();                                    // every wave is done reading the window of chunk c
+        STAMP(4, ts);
+        if constexpr (more) stash();
+        STAMP(5, ts);
+#ifdef PTTS_CONV_STAMPS
+        nchunk_done += 1;
+#endif
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::true_type{});
+    chunk(nchunks - 1, std::false_type{});
+#ifdef PTTS_CONV_STAMPS
+    if (tid == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_stamps[8 + i], tacc[i]);
+        atomicAdd(&g_conv_stamps[5], nchunk_done);
+        atomicAdd(&g_conv_stamps[6], __builtin_amdgcn_s_memtime() - ts_begin);
+    }
+#endif
+    wait_vmcnt<0>();                                      // the D clamped tail units: nothing may be in flight when the wave ends
+
+    // ---- epilogue (same as conv_kernel_h3) ----
+    const size_t obs = a.out_bs ? a.out_bs : (size_t)a.Tout * a.Cout;
+    float* outb = a.out + (size_t)b * obs;
+    const float* resb = a.res ? a.res + (size_t)b * obs : nullptr;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int u = u0 + w * RW + i * 16 + (lane & 15);
+        if (u >= a.U) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + 4 * (lane >> 4);
+            int t, co;
+            if (a.stride == 1) { t = u; co = n; }
+            else { const int r = n / a.Cout; co = n - r * a.Cout; t = a.stride * u - a.pad_t + r; }
+            if (t < 0 || t >= a.Tout) continue;
+            const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);      // N % TN == 0 and Cout % 16 == 0: whole quads
+            float4 y = make_float4(acc[i][j][0] + bs.x, acc[i][j][1] + bs.y, acc[i][j][2] + bs.z, acc[i][j][3] + bs.w);
+            if (resb) {
+                const float4 rv = *reinterpret_cast<const float4*>(resb + (size_t)t * a.Cout + co);
+                y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
+            }
+            if (a.act_out == 1) { y.x = tanhf(y.x); y.y = tanhf(y.y); y.z = tanhf(y.z); y.w = tanhf(y.w); }
+            *reinterpret_cast<float4*>(outb + (size_t)t * a.Cout + co) = y;
+        }
+    }
+}
+
+// unit image of the split weights: [N / TN][Cin / 32][taps] x { hi: TN rows x 64 B, lo: TN rows x 64 B }, 16-byte columns swizzled
+// as the LDS reads expect (swz16 of the row)
+__global__ void conv_units_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, uint4* __restrict__ out, int taps,
+                                  int N, int Cin, int TN) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte piece
+    const int nchunks = Cin / 32;
+    const size_t total = (size_t)(N / TN) * nchunks * taps * TN * 8;
+    if (idx >= total) return;
+    const int q = (int)(idx % 4);                 // stored column
+    const int n = (int)((idx / 4) % TN);
+    const int part = (int)((idx / (4 * (size_t)TN)) % 2);
+    const size_t unit = idx / (8 * (size_t)TN);
+    const int t = (int)(unit % taps), c = (int)((unit / taps) % nchunks), nb = (int)(unit / ((size_t)taps * nchunks));
+    const int qs = swz16(n, q);                   // the source column that lands in stored column q (the swizzle is an involution)
+    const _Float16* src = (part ? lo : hi) + ((size_t)t * N + (size_t)nb * TN + n) * Cin + c * 32 + 8 * qs;
+    out[idx] = *reinterpret_cast<const uint4*>(src);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -642,11 +953,25 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
 hipError_t conv_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<96, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3<96, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_stream_kernel<192, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
@@ -655,14 +980,36 @@ hipError_t conv_init() {
                                160 * 1024);
 }
 
-size_t conv_h3_lds(const ConvArgs& a, int TN) {
+size_t conv_h3_lds(const ConvArgs& a, int TN, int RW = 32) {
     const int lo = a.tstep >= 0 ? a.toff : a.toff + (a.taps - 1) * a.tstep;
     const int hi = a.tstep >= 0 ? a.toff + (a.taps - 1) * a.tstep : a.toff;
-    const int win = TM3 + (hi - lo);
+    const int win = 8 * RW + (hi - lo);
     return ((size_t)2 * win * LDH + (size_t)2 * a.taps * TN * LDH) * sizeof(_Float16);
 }
 
+#ifdef PTTS_CONV_STAMPS
+static hipError_t conv_launch_inner(const ConvArgs& a, hipStream_t s);
 hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), z, sizeof(z));
+    const hipError_t e = conv_launch_inner(a, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_conv_stamps), sizeof(z));
+    if (z[5] && z[8])
+        fprintf(stderr, "ring stamps Cin=%d N=%d taps=%d dil=%d U=%d: per chunk (cycles) dma-wait %.1f tap-barrier %.1f issue %.1f mfma %.1f chunk-barrier %.1f stash %.1f | chunks %llu kernel/wg %.0f\n",
+                a.Cin, a.N, a.taps, a.tstep, a.U, (double)z[8] / z[5], (double)z[9] / z[5], (double)z[10] / z[5], (double)z[11] / z[5],
+                (double)z[12] / z[5], (double)z[13] / z[5], z[5], (double)z[6] / ((double)z[5] / (a.Cin / 32)));
+    else if (z[5])
+        fprintf(stderr, "conv stamps Cin=%d N=%d taps=%d dil=%d U=%d: per chunk (s_memtime ticks) fetch %.1f mfma %.1f bar %.1f stash %.1f bar %.1f | chunks %llu kernel/wg %.0f\n",
+                a.Cin, a.N, a.taps, a.tstep, a.U, (double)z[0] / z[5], (double)z[1] / z[5], (double)z[2] / z[5], (double)z[3] / z[5],
+                (double)z[4] / z[5], z[5], (double)z[6] / ((double)z[5] / (a.Cin / 32)));
+    return e;
+}
+static hipError_t conv_launch_inner(const ConvArgs& a, hipStream_t s) {
+#else
+hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
+#endif
     if (a.taps > MAX_TAPS || a.Cin % KC != 0) return hipErrorInvalidValue;
     // last layer (one output channel, 7 taps): the reduction kernel
     if (getenv("PTTS_DAC_NO_LAST_KERNEL") == nullptr && a.Cout == 1 && a.N == 1 && a.taps == 7 && a.tstep == 1 && a.toff == -3 &&
@@ -692,16 +1039,55 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
         }
         return hipGetLastError();
     }
+    // LDS-DMA ring kernel: 64 rows per wave, unit image present, long enough launches
+    const bool no_ring = getenv("PTTS_DAC_NO_RING") != nullptr;          // A/B and the equivalence test
+    const int ring_taps = getenv("PTTS_DAC_RING_TAPS") ? atoi(getenv("PTTS_DAC_RING_TAPS")) : 7;   // bit 0: 7-tap, 1: 1x1, 2: transposed
+    const int ring_min_u = getenv("PTTS_DAC_RING_MIN_U") ? atoi(getenv("PTTS_DAC_RING_MIN_U")) : 1024;   // tests: 1
+    if (!no_ring && a.w_units && (a.unit_tn == 96 || a.unit_tn == 192) && a.N % a.unit_tn == 0 && a.Cin % KC3 == 0 && a.Cout % 4 == 0 &&
+        a.U >= ring_min_u && (a.taps == 7 || a.taps == 2 || a.taps == 1) && ((ring_taps >> (a.taps == 7 ? 0 : a.taps)) & 1)) {
+        const int span = (a.taps - 1) * (a.tstep >= 0 ? a.tstep : -a.tstep);
+        constexpr int RS = 4;
+        // 96 outputs x 64 rows per wave; few-tap layers (transposed, wide 1x1: the window is staged once per 1 - 2 units of MFMA
+        // work) take 192 outputs x 32 rows per wave, which halves the Snake / split work per MFMA
+        const int rw = a.unit_tn == 96 ? 64 : 32;
+        const size_t lds = (size_t)(8 * rw + span) * 128 + (size_t)RS * a.unit_tn * 128;
+        if (span <= h3_max_span(rw) && lds <= 160 * 1024 && (a.unit_tn == 96 || a.taps != 7)) {
+            dim3 grid(a.N / a.unit_tn, (a.U + 8 * rw - 1) / (8 * rw), a.B);
+            if (a.unit_tn == 96) {
+                if (a.taps == 7) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS>), grid, dim3(512), lds, s, a);
+                else if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 2, RS>), grid, dim3(512), lds, s, a);
+                else hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 1, RS>), grid, dim3(512), lds, s, a);
+            } else {
+                if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 2, RS>), grid, dim3(512), lds, s, a);
+                else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 1, RS>), grid, dim3(512), lds, s, a);
+            }
+            return hipGetLastError();
+        }
+    }
     if (a.w_hi && a.w_lo && a.Cin % KC3 == 0) {
         // TN = 96 when it divides N and fits LDS, else 64
         int TN = (a.N % 96 == 0 && conv_h3_lds(a, 96) <= 160 * 1024) ? 96 : 64;
         if (a.N % 64 != 0 && a.N % 96 != 0) TN = a.N <= 64 ? 64 : 96;
-        const size_t lds3 = conv_h3_lds(a, TN);
         const int span = (a.taps - 1) * (a.tstep >= 0 ? a.tstep : -a.tstep);
-        if (lds3 <= 160 * 1024 && TM3 + span <= 384) {     // 384 = window rows the register staging covers
-            dim3 grid((a.N + TN - 1) / TN, (a.U + TM3 - 1) / TM3, a.B);
-            if (TN == 64) hipLaunchKernelGGL(conv_kernel_h3<64>, grid, dim3(512), lds3, s, a);
-            else hipLaunchKernelGGL(conv_kernel_h3<96>, grid, dim3(512), lds3, s, a);
+        // 64 rows per wave (512-row workgroups) where the launch is long enough and the window fits
+        const char* tile = getenv("PTTS_DAC_TILE");          // "96x32" | "64x32" | "64x64" | "96x64": A/B and tests
+        int RW = 32;
+        if (tile) {
+            int tn = 0, rw = 0;
+            if (sscanf(tile, "%dx%d", &tn, &rw) == 2 && (tn == 64 || tn == 96) && (rw == 32 || rw == 64)) {
+                if (a.N % tn == 0) TN = tn;
+                RW = rw;
+            }
+        }
+        if (RW == 64 && (span > h3_max_span(64) || conv_h3_lds(a, TN, 64) > 160 * 1024 || a.U < 1024)) RW = 32;
+        const size_t lds3 = conv_h3_lds(a, TN, RW);
+        if (lds3 <= 160 * 1024 && span <= h3_max_span(RW)) {
+            const int tmw = 8 * RW;
+            dim3 grid((a.N + TN - 1) / TN, (a.U + tmw - 1) / tmw, a.B);
+            if (TN == 64 && RW == 32) hipLaunchKernelGGL((conv_kernel_h3<64, 32>), grid, dim3(512), lds3, s, a);
+            else if (TN == 96 && RW == 32) hipLaunchKernelGGL((conv_kernel_h3<96, 32>), grid, dim3(512), lds3, s, a);
+            else if (TN == 64) hipLaunchKernelGGL((conv_kernel_h3<64, 64>), grid, dim3(512), lds3, s, a);
+            else hipLaunchKernelGGL((conv_kernel_h3<96, 64>), grid, dim3(512), lds3, s, a);
             return hipGetLastError();
         }
     }
@@ -734,6 +1120,14 @@ hipError_t conv_pack_launch(const float* w, float* out, int Cout, int Cin, int k
     size_t total = (size_t)(transposed ? 2 : k) * N * Cin;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, Cout, Cin, k,
                        transposed, stride, N);
+    return hipGetLastError();
+}
+
+hipError_t conv_units_launch(const void* hi, const void* lo, void* out, int taps, int N, int Cin, int TN, hipStream_t s) {
+    if (N % TN != 0 || Cin % 32 != 0) return hipErrorInvalidValue;
+    const size_t total = (size_t)(N / TN) * (Cin / 32) * taps * TN * 8;
+    hipLaunchKernelGGL(conv_units_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const _Float16*)hi, (const _Float16*)lo,
+                       (uint4*)out, taps, N, Cin, TN);
     return hipGetLastError();
 }
 

@@ -74,6 +74,8 @@ struct T5Layer {
 struct ConvLayer {
     float *w = nullptr, *bias = nullptr, *alpha = nullptr;   // packed weight, bias, Snake alpha of the INPUT
     void *w_hi = nullptr, *w_lo = nullptr;                    // fp16 hi/lo split of `w` (fast conv path)
+    void* w_units = nullptr;                                  // the same halves as LDS-DMA units of unit_tn outputs (conv.h), decoder only
+    int unit_tn = 0;
     int Cin = 0, Cout = 0, k = 1, dil = 1, stride = 1;
     bool transposed = false, have_w = false, have_b = false, have_a = false, needs_alpha = false;
     bool strided = false;   // encoder down-sampling conv (kernel 2*stride): run as a 3-tap conv over the [T/s][s*Cin] view
@@ -725,6 +727,14 @@ int load_dac_tensor(ptts_engine* e, const std::string& n, const float* data, con
             const size_t n = (size_t)taps * N * L.Cin;
             if (!L.w_hi) { PTTS_TRY(dev_alloc(e, &L.w_hi, n * 2)); PTTS_TRY(dev_alloc(e, &L.w_lo, n * 2)); }
             HIP_TRY(split_halves_launch(L.w, L.w_hi, L.w_lo, n, s));
+            // few-tap layers (transposed, 1x1) take 192-wide units where they divide N, everything else 96-wide ones
+            const bool no192 = getenv("PTTS_DAC_NO_UNIT192") != nullptr;      // A/B and the equivalence test
+            const int tn = (taps <= 2 && N % 192 == 0 && !no192) ? 192 : (N % 96 == 0 ? 96 : 0);
+            if (tn) {
+                if (!L.w_units) PTTS_TRY(dev_alloc(e, &L.w_units, n * 4));
+                HIP_TRY(conv_units_launch(L.w_hi, L.w_lo, L.w_units, taps, N, L.Cin, tn, s));
+                L.unit_tn = tn;
+            }
         }
         L.have_w = true;
         return PTTS_OK;
@@ -1428,6 +1438,7 @@ int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, 
             const bool last = i + 1 == e->dac.size();
             ConvArgs a;
             a.in = cur; a.w = L.w; a.w_hi = L.w_hi; a.w_lo = L.w_lo; a.bias = L.bias; a.alpha = L.needs_alpha ? L.alpha : nullptr;
+            a.w_units = L.w_units; a.unit_tn = L.unit_tn;
             a.B = nb; a.Tin = T; a.Cin = L.Cin; a.Cout = L.Cout;
             if (L.transposed) {
                 a.Tout = T * L.stride; a.N = L.stride * L.Cout; a.U = T + 1; a.taps = 2; a.tstep = -1; a.toff = 0;

@@ -702,6 +702,40 @@ def test_dac_streaming_1x1_conv_equals_the_tiled_kernel(hip):
     assert float((a - c).abs().max()) < 5e-6 and float(a.abs().max()) > 0.05
 
 
+def test_dac_ring_kernel_equals_the_tiled_kernel(hip):
+    """The wide layers run on conv_kernel_h3r (weights by LDS-DMA through a ring of tap units, counted vmcnt waits, 64 rows per
+    wave; 192-wide units for the transposed and 1x1 layers): same products in the same order as conv_kernel_h3, so the waveform
+    must be bit-identical with PTTS_DAC_NO_RING=1 - at 40 frames (every workgroup is mostly padding: row masks, clamped tail
+    units) and at 700 frames (several 512-row workgroups per layer, halos across their seams), for both unit widths."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
+    os.environ["PTTS_DAC_RING_MIN_U"] = "1"
+    try:
+        dac = DACModel(cfg, sd, device="cuda:0")
+        os.environ["PTTS_DAC_NO_UNIT192"] = "1"
+        try:
+            dac96 = DACModel(cfg, sd, device="cuda:0")      # the unit width is chosen when the weights are loaded
+        finally:
+            del os.environ["PTTS_DAC_NO_UNIT192"]
+        for shape in ((1, 2, 9, 40), (1, 1, 9, 700)):
+            codes = torch.randint(0, 1024, shape, generator=torch.Generator().manual_seed(shape[-1]))
+            a = dac.decode(codes, None).audio_values.cpu()
+            b = dac96.decode(codes, None).audio_values.cpu()
+            os.environ["PTTS_DAC_NO_RING"] = "1"
+            try:
+                ref = dac.decode(codes, None).audio_values.cpu()
+            finally:
+                del os.environ["PTTS_DAC_NO_RING"]
+            assert float(ref.abs().max()) > 0.05
+            assert torch.equal(a, ref), ("192/96-wide units", shape, float((a - ref).abs().max()))
+            assert torch.equal(b, ref), ("96-wide units", shape, float((b - ref).abs().max()))
+    finally:
+        del os.environ["PTTS_DAC_RING_MIN_U"]
+
+
 def test_dac_decode_long_clip_chunked_equals_unchunked(hip):
     """time tiles, halos across tile seams and batch chunks: a long clip decoded alone must equal the same
     clip decoded inside a batch (size-independent property used at the BASELINE sizes)."""
