@@ -551,6 +551,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
                 int ps = slot + D; if (ps >= RS) ps -= RS;
                 dma(c * TAPS + t + D, ps);                // into the slot unit u - 1 was read from
             }
+            asm volatile("" ::: "memory");                // the tables assume the DMA pieces are issued BEFORE this tap's activation loads
             if constexpr (more) {
 #pragma unroll
                 for (int k = 0; k < XA; ++k) if (k % TAPS == t) xload(k, cn);
