@@ -10,6 +10,11 @@ struct ConvArgs {
     const void* w_lo = nullptr;
     const void* w_units = nullptr; // the split weights as LDS-DMA units [N / unit_tn][Cin / 32][taps][hi | lo][unit_tn][32] (conv_units_launch), or null
     int unit_tn = 0;
+    // fused residual unit (conv_kernel_h3r, C = unit_tn = 96): out = in + bias2 + W2 . snake_alpha2(bias + conv7(snake_alpha(in)));
+    // w2_units = the 1x1 weights as A fragments in the accumulator's k order (conv_units2_launch); `res` stays null, out != in
+    const void* w2_units = nullptr;
+    const float* bias2 = nullptr;
+    const float* alpha2 = nullptr;
     const float* bias = nullptr;   // [Cout]
     const float* alpha = nullptr;  // [Cin] Snake on the input, or null
     const float* res = nullptr;    // residual, same shape as out, or null (may alias out)
@@ -31,6 +36,8 @@ hipError_t dac_table_launch(const float* codebook, const float* proj_w, const fl
 // same bytes as w_hi + w_lo, regrouped so that one tap of one 32-channel chunk of one TN-wide output block is contiguous and
 // already in the swizzled order the kernel reads from LDS
 hipError_t conv_units_launch(const void* hi, const void* lo, void* out, int taps, int N, int Cin, int TN, hipStream_t s);
+// the split [C][C] weights of a 1x1 conv as stage-2 units of the fused residual unit
+hipError_t conv_units2_launch(const void* hi, const void* lo, void* out, int C, hipStream_t s);
 hipError_t split_halves_launch(const float* src, void* hi, void* lo, size_t n, hipStream_t s);
 hipError_t conv_pack_launch(const float* w, float* out, int Cout, int Cin, int k, int transposed, int stride, int N,
                             hipStream_t s);

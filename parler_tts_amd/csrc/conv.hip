@@ -431,9 +431,18 @@ struct H3R {
     static constexpr int n_min = G * (D - 1);              // only the DMA pieces of the units in between: always a lower bound
 };
 
-template <int TN, int RW, int TAPS, int RS>
+// FUSE (a residual unit whose channels fit one output block, C = TN = 96: HF modeling_dac.py:175-210 x + conv1(snake(conv7(snake(x))))):
+// the 7-tap conv's tile never leaves the registers.  The accumulators (lane = (channel quad g, row t): channels 16 j + 4 g .. + 3)
+// get the bias, the 1x1 conv's Snake and the fp16 split and ARE the B operand of the second MFMA stage: a k-step of 32 channels
+// takes the lane's quads of blocks 2 m and 2 m + 1, i.e. k position 8 g + e holds channel 32 m + 4 g + e (e < 4) or
+// 32 m + 16 + 4 g + e - 4 - a permutation of the step's channels, so the 1x1 weights are stored as A fragments in that k order
+// (conv_units2_kernel) and nothing moves between lanes.  The fragments arrive as KS more units through the same ring (instead
+// of the clamped tail units).  h is neither written (8 GB per layer at C = 96) nor read back, and one launch goes away.
+// The sum over a k-step runs in another channel order than in the separate 1x1 kernel: equal to ~1e-7 relative, not bit for bit.
+template <int TN, int RW, int TAPS, int RS, bool FUSE>
 __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     using K = H3R<TN, RW, TAPS, RS>;
+    static_assert(!FUSE || (TN % 32 == 0 && RS > TN / 32 && RW % 32 == 0), "fused 1x1 stage: all its k-step units sit in the ring at once");
     constexpr int NT = K::NT, NI = K::NI, TMW = K::TMW, D = K::D, UB = K::UB, GS = K::GS, XA = K::XA;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -501,6 +510,8 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     auto dma = [&](int u, int slot) {
         const int uc = u < nunits ? u : nunits - 1;
         const char* src = units + (size_t)uc * UB + (size_t)tid * GS;
+        if constexpr (FUSE)                               // units nunits .. nunits + KS - 1: the A fragments of the fused 1x1 stage
+            if (u >= nunits) src = reinterpret_cast<const char*>(a.w2_units) + (size_t)(u - nunits < TN / 32 ? u - nunits : 0) * UB + (size_t)tid * GS;
         char* dst = ring + slot * UB + w * (64 * GS);
 #if defined(PTTS_RING_DEBUG_COPY)         // diagnostic build: the same pieces moved through registers (tells a layout bug from a DMA one)
 #pragma unroll
@@ -602,7 +613,83 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
         atomicAdd(&g_conv_stamps[6], __builtin_amdgcn_s_memtime() - ts_begin);
     }
 #endif
-    wait_vmcnt<0>();                                      // the D clamped tail units: nothing may be in flight when the wave ends
+    wait_vmcnt<0>();                                      // the D tail units: nothing may be in flight when the wave ends
+
+    if constexpr (FUSE) {
+        constexpr int KS = TN / 32;
+        static_assert(D >= KS, "the tail prefetch covers the stage-2 units");
+        // the 1x1 conv's Snake table over the dead activation window
+        lds_barrier();                                    // the DMA pieces of the stage-2 units are in LDS; the window is dead
+        float* als = reinterpret_cast<float*>(xh);        // [TN] alpha, [TN] 1 / (alpha + 1e-9)
+        float* ivs = als + TN;
+        for (int i = tid; i < TN; i += 512) { const float al = a.alpha2[i]; als[i] = al; ivs[i] = 1.0f / (al + 1e-9f); }
+        lds_barrier();
+        const int g = lane >> 4;
+        const size_t obs2 = (size_t)a.Tout * a.Cout;
+        float* outb2 = a.out + (size_t)b * obs2;
+        int s2[KS];                                       // ring slot of stage-2 unit m (slot = the one after the last conv unit)
+#pragma unroll
+        for (int m = 0; m < KS; ++m) { int q = slot + m; if (q >= RS) q -= RS; s2[m] = q; }
+#pragma unroll
+        for (int ip = 0; ip < NI; ip += 2) {              // two row tiles at a time: an A fragment read feeds 6 MFMAs
+            half8 bh[2][KS], bl[2][KS];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int m = 0; m < KS; ++m)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {      // the lane's quad of block 2 m + hb -> k positions 4 hb .. 4 hb + 3
+                        const int j = 2 * m + hb, ch = 16 * j + 4 * g;
+                        const float4 b1 = *reinterpret_cast<const float4*>(a.bias + ch);
+                        const f32x4 al = *reinterpret_cast<const f32x4*>(als + ch), iv = *reinterpret_cast<const f32x4*>(ivs + ch);
+                        const float bq[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float hval = acc[ip + ii][j][r] + bq[r];         // h as the 7-tap conv would have stored it
+                            _Float16 h, l;
+                            split_h(snake_f(hval, al[r], iv[r]), h, l);
+                            bh[ii][m][4 * hb + r] = h;
+                            bl[ii][m][4 * hb + r] = l;
+                        }
+                    }
+            f32x4 acc2[2][NT];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int jb = 0; jb < NT; ++jb) acc2[ii][jb] = {0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < KS; ++m) {
+                const half8* fh = reinterpret_cast<const half8*>(ring + s2[m] * UB);   // [jb][lane] hi, then [jb][lane] lo
+                const half8* fl = fh + NT * 64;
+#pragma unroll
+                for (int jb = 0; jb < NT; ++jb) {
+                    const half8 ah = fh[jb * 64 + lane], alo = fl[jb * 64 + lane];
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {      // same product order as the separate kernels: lo.hi, hi.lo, hi.hi
+                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh[ii][m], acc2[ii][jb], 0, 0, 0);
+                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ii][m], acc2[ii][jb], 0, 0, 0);
+                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ii][m], acc2[ii][jb], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int u = u0 + w * RW + (ip + ii) * 16 + (lane & 15);
+                if (u >= a.U) continue;
+#pragma unroll
+                for (int jb = 0; jb < NT; ++jb) {
+                    const int co = 16 * jb + 4 * g;
+                    const float4 b2 = *reinterpret_cast<const float4*>(a.bias2 + co);
+                    const float4 rv = *reinterpret_cast<const float4*>(inb + (size_t)u * a.Cin + co);      // the unit's input x
+                    float4 y;
+                    y.x = (acc2[ii][jb][0] + b2.x) + rv.x; y.y = (acc2[ii][jb][1] + b2.y) + rv.y;
+                    y.z = (acc2[ii][jb][2] + b2.z) + rv.z; y.w = (acc2[ii][jb][3] + b2.w) + rv.w;
+                    *reinterpret_cast<float4*>(outb2 + (size_t)u * a.Cout + co) = y;
+                }
+            }
+        }
+        return;
+    }
 
     // ---- epilogue (same as conv_kernel_h3) ----
     const size_t obs = a.out_bs ? a.out_bs : (size_t)a.Tout * a.Cout;
@@ -629,6 +716,22 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
             *reinterpret_cast<float4*>(outb + (size_t)t * a.Cout + co) = y;
         }
     }
+}
+
+// A fragments of a fused 1x1 stage (C -> C): unit m = k-step m: { hi: [C / 16 blocks][64 lanes] x 16 B, lo: same }; lane (g = l >> 4,
+// n = l & 15) of block jb holds W[16 jb + n][channel of k position 8 g + e], e = 0 .. 7, with the accumulator's channel order
+// channel = 32 m + 4 g + e (e < 4), 32 m + 16 + 4 g + (e - 4) (e >= 4)
+__global__ void conv_units2_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, uint4* __restrict__ out, int C) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte fragment
+    const int NB = C / 16;
+    const size_t total = (size_t)(C / 32) * 2 * NB * 64;
+    if (idx >= total) return;
+    const int l = (int)(idx % 64), jb = (int)((idx / 64) % NB), part = (int)((idx / (64 * (size_t)NB)) % 2), m = (int)(idx / (128 * (size_t)NB));
+    const int g = l >> 4, n = 16 * jb + (l & 15);
+    const _Float16* row = (part ? lo : hi) + (size_t)n * C + 32 * m;
+    _Float16 v[8];
+    for (int e = 0; e < 4; ++e) { v[e] = row[4 * g + e]; v[4 + e] = row[16 + 4 * g + e]; }
+    out[idx] = *reinterpret_cast<uint4*>(v);
 }
 
 // unit image of the split weights: [N / TN][Cin / 32][taps] x { hi: TN rows x 64 B, lo: TN rows x 64 B }, 16-byte columns swizzled
@@ -964,15 +1067,17 @@ hipError_t conv_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 1, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 1, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_stream_kernel<192, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
@@ -1044,8 +1149,9 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     const bool no_ring = getenv("PTTS_DAC_NO_RING") != nullptr;          // A/B and the equivalence test
     const int ring_taps = getenv("PTTS_DAC_RING_TAPS") ? atoi(getenv("PTTS_DAC_RING_TAPS")) : 7;   // bit 0: 7-tap, 1: 1x1, 2: transposed
     const int ring_min_u = getenv("PTTS_DAC_RING_MIN_U") ? atoi(getenv("PTTS_DAC_RING_MIN_U")) : 1024;   // tests: 1
+    if (a.w2_units && (no_ring || !a.w_units)) return hipErrorInvalidValue;          // the fused unit exists on the ring kernel only
     if (!no_ring && a.w_units && (a.unit_tn == 96 || a.unit_tn == 192) && a.N % a.unit_tn == 0 && a.Cin % KC3 == 0 && a.Cout % 4 == 0 &&
-        a.U >= ring_min_u && (a.taps == 7 || a.taps == 2 || a.taps == 1) && ((ring_taps >> (a.taps == 7 ? 0 : a.taps)) & 1)) {
+        (a.U >= ring_min_u || a.w2_units) && (a.taps == 7 || a.taps == 2 || a.taps == 1) && ((ring_taps >> (a.taps == 7 ? 0 : a.taps)) & 1)) {
         const int span = (a.taps - 1) * (a.tstep >= 0 ? a.tstep : -a.tstep);
         constexpr int RS = 4;
         // 96 outputs x 64 rows per wave; few-tap layers (transposed, wide 1x1: the window is staged once per 1 - 2 units of MFMA
@@ -1054,13 +1160,20 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
         const size_t lds = (size_t)(8 * rw + span) * 128 + (size_t)RS * a.unit_tn * 128;
         if (span <= h3_max_span(rw) && lds <= 160 * 1024 && (a.unit_tn == 96 || a.taps != 7)) {
             dim3 grid(a.N / a.unit_tn, (a.U + 8 * rw - 1) / (8 * rw), a.B);
+            if (a.w2_units) {     // fused residual unit: one output block holds every channel, dense tensors, distinct output
+                if (a.unit_tn != 96 || a.taps != 7 || a.N != 96 || a.Cin != 96 || a.Cout != 96 || !a.alpha2 || !a.bias2 || a.res || a.in_bs ||
+                    a.out_bs || a.out == a.in || a.stride != 1 || a.act_out)
+                    return hipErrorInvalidValue;
+                hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
+                return hipGetLastError();
+            }
             if (a.unit_tn == 96) {
-                if (a.taps == 7) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS>), grid, dim3(512), lds, s, a);
-                else if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 2, RS>), grid, dim3(512), lds, s, a);
-                else hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 1, RS>), grid, dim3(512), lds, s, a);
+                if (a.taps == 7) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, false>), grid, dim3(512), lds, s, a);
+                else if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 2, RS, false>), grid, dim3(512), lds, s, a);
+                else hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 1, RS, false>), grid, dim3(512), lds, s, a);
             } else {
-                if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 2, RS>), grid, dim3(512), lds, s, a);
-                else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 1, RS>), grid, dim3(512), lds, s, a);
+                if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 2, RS, false>), grid, dim3(512), lds, s, a);
+                else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 1, RS, false>), grid, dim3(512), lds, s, a);
             }
             return hipGetLastError();
         }
@@ -1121,6 +1234,14 @@ hipError_t conv_pack_launch(const float* w, float* out, int Cout, int Cin, int k
     size_t total = (size_t)(transposed ? 2 : k) * N * Cin;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, Cout, Cin, k,
                        transposed, stride, N);
+    return hipGetLastError();
+}
+
+hipError_t conv_units2_launch(const void* hi, const void* lo, void* out, int C, hipStream_t s) {
+    if (C % 32 != 0) return hipErrorInvalidValue;
+    const size_t total = (size_t)(C / 32) * 2 * (C / 16) * 64;
+    hipLaunchKernelGGL(conv_units2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const _Float16*)hi, (const _Float16*)lo,
+                       (uint4*)out, C);
     return hipGetLastError();
 }
 

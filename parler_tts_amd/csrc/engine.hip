@@ -76,6 +76,7 @@ struct ConvLayer {
     void *w_hi = nullptr, *w_lo = nullptr;                    // fp16 hi/lo split of `w` (fast conv path)
     void* w_units = nullptr;                                  // the same halves as LDS-DMA units of unit_tn outputs (conv.h), decoder only
     int unit_tn = 0;
+    void* w2_units = nullptr;                                 // a 1x1 conv's weights as stage-2 units of the fused residual unit (C = 96)
     int Cin = 0, Cout = 0, k = 1, dil = 1, stride = 1;
     bool transposed = false, have_w = false, have_b = false, have_a = false, needs_alpha = false;
     bool strided = false;   // encoder down-sampling conv (kernel 2*stride): run as a 3-tap conv over the [T/s][s*Cin] view
@@ -734,6 +735,10 @@ int load_dac_tensor(ptts_engine* e, const std::string& n, const float* data, con
                 if (!L.w_units) PTTS_TRY(dev_alloc(e, &L.w_units, n * 4));
                 HIP_TRY(conv_units_launch(L.w_hi, L.w_lo, L.w_units, taps, N, L.Cin, tn, s));
                 L.unit_tn = tn;
+            }
+            if (!L.transposed && L.k == 1 && L.Cin == 96 && L.Cout == 96) {
+                if (!L.w2_units) PTTS_TRY(dev_alloc(e, &L.w2_units, n * 4));
+                HIP_TRY(conv_units2_launch(L.w_hi, L.w_lo, L.w2_units, 96, s));
             }
         }
         L.have_w = true;
@@ -1426,6 +1431,8 @@ int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, 
     }
     int hop = 1;
     for (int i = 0; i < c.dac_n_up; ++i) hop *= c.dac_up[i];
+    const bool fuse_units = getenv("PTTS_DAC_NO_FUSE") == nullptr && getenv("PTTS_DAC_NO_RING") == nullptr &&
+                            getenv("PTTS_DAC_RING_TAPS") == nullptr;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0 < chunk) ? B - b0 : chunk;
         float* cur = e->dac_buf0;
@@ -1450,6 +1457,17 @@ int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, 
                 if (is_res_conv1) { a.out = nxt; a.res = nxt; }
                 else a.out = last ? out + (size_t)b0 * F * hop : nxt;
                 if (last) a.act_out = 1;
+            }
+            // residual unit whose channels fit one output block: conv7 -> snake -> conv1 -> + x in one launch (conv.h, w2_units)
+            if (fuse_units && !L.transposed && L.k == 7 && !last && L.unit_tn == 96 && L.Cin == 96 && L.Cout == 96 && 6 * L.dil <= 64 &&
+                e->dac[i + 1].k == 1 && e->dac[i + 1].w2_units) {
+                const ConvLayer& L1 = e->dac[i + 1];
+                a.out = nxt; a.res = nullptr;
+                a.w2_units = L1.w2_units; a.bias2 = L1.bias; a.alpha2 = L1.alpha;
+                HIP_TRY(conv_launch(a, s));
+                std::swap(cur, nxt);
+                ++i;
+                continue;
             }
             HIP_TRY(conv_launch(a, s));
             if (L.transposed) { T = a.Tout; std::swap(cur, nxt); }

@@ -713,6 +713,7 @@ def test_dac_ring_kernel_equals_the_tiled_kernel(hip):
     cfg = config_for("dac_mini")
     sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
     os.environ["PTTS_DAC_RING_MIN_U"] = "1"
+    os.environ["PTTS_DAC_NO_FUSE"] = "1"       # the fused residual unit has its own (rounding-level) test below
     try:
         dac = DACModel(cfg, sd, device="cuda:0")
         os.environ["PTTS_DAC_NO_UNIT192"] = "1"
@@ -732,6 +733,33 @@ def test_dac_ring_kernel_equals_the_tiled_kernel(hip):
             assert float(ref.abs().max()) > 0.05
             assert torch.equal(a, ref), ("192/96-wide units", shape, float((a - ref).abs().max()))
             assert torch.equal(b, ref), ("96-wide units", shape, float((b - ref).abs().max()))
+    finally:
+        del os.environ["PTTS_DAC_RING_MIN_U"]
+        del os.environ["PTTS_DAC_NO_FUSE"]
+
+
+def test_dac_fused_residual_unit_equals_the_two_kernels(hip):
+    """C = 96 residual units run as ONE launch (7-tap conv tile kept in registers -> bias, Snake, fp16 split -> B operand of the 1x1
+    stage -> + x).  The 1x1 stage sums a k-step's 32 channels in the accumulator's channel order, so it agrees with the
+    two-kernel path to rounding (not bit for bit): the waveform has to stay within 2e-6 of it, 40 frames (edge masks) and 700."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
+    os.environ["PTTS_DAC_RING_MIN_U"] = "1"
+    try:
+        dac = DACModel(cfg, sd, device="cuda:0")
+        for shape in ((1, 2, 9, 40), (1, 1, 9, 700)):
+            codes = torch.randint(0, 1024, shape, generator=torch.Generator().manual_seed(shape[-1]))
+            a = dac.decode(codes, None).audio_values.cpu()
+            os.environ["PTTS_DAC_NO_FUSE"] = "1"
+            try:
+                ref = dac.decode(codes, None).audio_values.cpu()
+            finally:
+                del os.environ["PTTS_DAC_NO_FUSE"]
+            assert float(ref.abs().max()) > 0.05
+            assert float((a - ref).abs().max()) < 2e-6, (shape, float((a - ref).abs().max()))
     finally:
         del os.environ["PTTS_DAC_RING_MIN_U"]
 
