@@ -442,7 +442,7 @@ struct H3R {
 template <int TN, int RW, int TAPS, int RS, bool FUSE>
 __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     using K = H3R<TN, RW, TAPS, RS>;
-    static_assert(!FUSE || (TN % 32 == 0 && RS > TN / 32 && RW % 32 == 0), "fused 1x1 stage: all its k-step units sit in the ring at once");
+    static_assert(!FUSE || (TN % 32 == 0 && RW % 32 == 0), "fused 1x1 stage: k-steps of 32 channels, row tiles in pairs");
     constexpr int NT = K::NT, NI = K::NI, TMW = K::TMW, D = K::D, UB = K::UB, GS = K::GS, XA = K::XA;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -613,80 +613,125 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
         atomicAdd(&g_conv_stamps[6], __builtin_amdgcn_s_memtime() - ts_begin);
     }
 #endif
-    wait_vmcnt<0>();                                      // the D tail units: nothing may be in flight when the wave ends
+    if constexpr (!FUSE) wait_vmcnt<0>();                 // the D clamped tail units: nothing may be in flight when the wave ends
 
     if constexpr (FUSE) {
         constexpr int KS = TN / 32;
-        static_assert(D >= KS, "the tail prefetch covers the stage-2 units");
         // the 1x1 conv's Snake table over the dead activation window
-        lds_barrier();                                    // the DMA pieces of the stage-2 units are in LDS; the window is dead
+        lds_barrier();                                    // everyone is out of the last chunk: the window is dead
         float* als = reinterpret_cast<float*>(xh);        // [TN] alpha, [TN] 1 / (alpha + 1e-9)
         float* ivs = als + TN;
         for (int i = tid; i < TN; i += 512) { const float al = a.alpha2[i]; als[i] = al; ivs[i] = 1.0f / (al + 1e-9f); }
-        lds_barrier();
         const int g = lane >> 4;
         const size_t obs2 = (size_t)a.Tout * a.Cout;
         float* outb2 = a.out + (size_t)b * obs2;
-        int s2[KS];                                       // ring slot of stage-2 unit m (slot = the one after the last conv unit)
+        // B fragments of k-step m for row tile i: the lane's quads of blocks 2 m and 2 m + 1 (+ bias, Snake, split)
+        auto bfrag = [&](int i, int m, half8& bh, half8& bl) {
 #pragma unroll
-        for (int m = 0; m < KS; ++m) { int q = slot + m; if (q >= RS) q -= RS; s2[m] = q; }
+            for (int hb = 0; hb < 2; ++hb) {
+                const int j = 2 * m + hb, ch = 16 * j + 4 * g;
+                const float4 b1 = *reinterpret_cast<const float4*>(a.bias + ch);
+                const f32x4 al = *reinterpret_cast<const f32x4*>(als + ch), iv = *reinterpret_cast<const f32x4*>(ivs + ch);
+                const float bq[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int ip = 0; ip < NI; ip += 2) {              // two row tiles at a time: an A fragment read feeds 6 MFMAs
-            half8 bh[2][KS], bl[2][KS];
+                for (int r = 0; r < 4; ++r) {
+                    const float hval = acc[i][j][r] + bq[r];                 // h as the 7-tap conv would have stored it
+                    _Float16 h, l;
+                    split_h(snake_f(hval, al[r], iv[r]), h, l);
+                    bh[4 * hb + r] = h;
+                    bl[4 * hb + r] = l;
+                }
+            }
+        };
+        auto store_tile = [&](int i, const f32x4 (&o)[NT]) {
+            const int u = u0 + w * RW + i * 16 + (lane & 15);
+            if (u >= a.U) return;
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+            for (int jb = 0; jb < NT; ++jb) {
+                const int co = 16 * jb + 4 * g;
+                const float4 b2 = *reinterpret_cast<const float4*>(a.bias2 + co);
+                const float4 rv = *reinterpret_cast<const float4*>(inb + (size_t)u * a.Cin + co);      // the unit's input x
+                float4 y;
+                y.x = (o[jb][0] + b2.x) + rv.x; y.y = (o[jb][1] + b2.y) + rv.y;
+                y.z = (o[jb][2] + b2.z) + rv.z; y.w = (o[jb][3] + b2.w) + rv.w;
+                *reinterpret_cast<float4*>(outb2 + (size_t)u * a.Cout + co) = y;
+            }
+        };
+        if constexpr (KS <= D) {
+            // every stage-2 unit is already in the ring (the tail prefetch fetched them): two row tiles at a time, so that an
+            // A fragment read feeds 6 MFMAs and the second accumulator set stays at 2 NT registers quads
+            wait_vmcnt<0>();
+            lds_barrier();                                // everyone's DMA pieces and the Snake table are in LDS
+            int s2[KS];
 #pragma unroll
-                for (int m = 0; m < KS; ++m)
+            for (int m = 0; m < KS; ++m) { int q = slot + m; if (q >= RS) q -= RS; s2[m] = q; }
 #pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {      // the lane's quad of block 2 m + hb -> k positions 4 hb .. 4 hb + 3
-                        const int j = 2 * m + hb, ch = 16 * j + 4 * g;
-                        const float4 b1 = *reinterpret_cast<const float4*>(a.bias + ch);
-                        const f32x4 al = *reinterpret_cast<const f32x4*>(als + ch), iv = *reinterpret_cast<const f32x4*>(ivs + ch);
-                        const float bq[4] = {b1.x, b1.y, b1.z, b1.w};
+            for (int ip = 0; ip < NI; ip += 2) {
+                half8 bh[2][KS], bl[2][KS];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float hval = acc[ip + ii][j][r] + bq[r];         // h as the 7-tap conv would have stored it
-                            _Float16 h, l;
-                            split_h(snake_f(hval, al[r], iv[r]), h, l);
-                            bh[ii][m][4 * hb + r] = h;
-                            bl[ii][m][4 * hb + r] = l;
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int m = 0; m < KS; ++m) bfrag(ip + ii, m, bh[ii][m], bl[ii][m]);
+                f32x4 acc2[2][NT];
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int jb = 0; jb < NT; ++jb) acc2[ii][jb] = {0, 0, 0, 0};
+#pragma unroll
+                for (int m = 0; m < KS; ++m) {
+                    const half8* fh = reinterpret_cast<const half8*>(ring + s2[m] * UB);   // [jb][lane] hi, then [jb][lane] lo
+                    const half8* fl = fh + NT * 64;
+#pragma unroll
+                    for (int jb = 0; jb < NT; ++jb) {
+                        const half8 ah = fh[jb * 64 + lane], alo = fl[jb * 64 + lane];
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {  // same product order as the separate kernels: lo.hi, hi.lo, hi.hi
+                            acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh[ii][m], acc2[ii][jb], 0, 0, 0);
+                            acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ii][m], acc2[ii][jb], 0, 0, 0);
+                            acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ii][m], acc2[ii][jb], 0, 0, 0);
                         }
                     }
-            f32x4 acc2[2][NT];
+                }
+                store_tile(ip, acc2[0]);
+                store_tile(ip + 1, acc2[1]);
+            }
+        } else {
+            // more stage-2 units than the ring holds: they keep streaming, one k-step per ring step, every row tile accumulates
+            static_assert(NI == 2, "streamed stage 2 keeps a second accumulator set for every row tile");
+            f32x4 acc2[NI][NT];
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+            for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
                 for (int jb = 0; jb < NT; ++jb) acc2[ii][jb] = {0, 0, 0, 0};
+            static_for<0, KS>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                wait_vmcnt<K::n_min>();                   // only DMA pieces are in flight: the D - 1 younger units stay
+                lds_barrier();                            // (m = 0: also publishes the Snake table)
+                {
+                    int ps = slot + D; if (ps >= RS) ps -= RS;
+                    dma(nunits + m + D, ps);
+                }
+                asm volatile("" ::: "memory");
+                half8 bh[NI], bl[NI];
 #pragma unroll
-            for (int m = 0; m < KS; ++m) {
-                const half8* fh = reinterpret_cast<const half8*>(ring + s2[m] * UB);   // [jb][lane] hi, then [jb][lane] lo
+                for (int ii = 0; ii < NI; ++ii) bfrag(ii, m, bh[ii], bl[ii]);
+                const half8* fh = reinterpret_cast<const half8*>(ring + slot * UB);
                 const half8* fl = fh + NT * 64;
 #pragma unroll
                 for (int jb = 0; jb < NT; ++jb) {
                     const half8 ah = fh[jb * 64 + lane], alo = fl[jb * 64 + lane];
 #pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {      // same product order as the separate kernels: lo.hi, hi.lo, hi.hi
-                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh[ii][m], acc2[ii][jb], 0, 0, 0);
-                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ii][m], acc2[ii][jb], 0, 0, 0);
-                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ii][m], acc2[ii][jb], 0, 0, 0);
+                    for (int ii = 0; ii < NI; ++ii) {
+                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh[ii], acc2[ii][jb], 0, 0, 0);
+                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ii], acc2[ii][jb], 0, 0, 0);
+                        acc2[ii][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ii], acc2[ii][jb], 0, 0, 0);
                     }
                 }
-            }
+                if (++slot == RS) slot = 0;
+            });
+            wait_vmcnt<0>();
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int u = u0 + w * RW + (ip + ii) * 16 + (lane & 15);
-                if (u >= a.U) continue;
-#pragma unroll
-                for (int jb = 0; jb < NT; ++jb) {
-                    const int co = 16 * jb + 4 * g;
-                    const float4 b2 = *reinterpret_cast<const float4*>(a.bias2 + co);
-                    const float4 rv = *reinterpret_cast<const float4*>(inb + (size_t)u * a.Cin + co);      // the unit's input x
-                    float4 y;
-                    y.x = (acc2[ii][jb][0] + b2.x) + rv.x; y.y = (acc2[ii][jb][1] + b2.y) + rv.y;
-                    y.z = (acc2[ii][jb][2] + b2.z) + rv.z; y.w = (acc2[ii][jb][3] + b2.w) + rv.w;
-                    *reinterpret_cast<float4*>(outb2 + (size_t)u * a.Cout + co) = y;
-                }
-            }
+            for (int ii = 0; ii < NI; ++ii) store_tile(ii, acc2[ii]);
         }
         return;
     }
@@ -1075,6 +1120,10 @@ hipError_t conv_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 7, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 1, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1158,13 +1207,14 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
         // work) take 192 outputs x 32 rows per wave, which halves the Snake / split work per MFMA
         const int rw = a.unit_tn == 96 ? 64 : 32;
         const size_t lds = (size_t)(8 * rw + span) * 128 + (size_t)RS * a.unit_tn * 128;
-        if (span <= h3_max_span(rw) && lds <= 160 * 1024 && (a.unit_tn == 96 || a.taps != 7)) {
+        if (span <= h3_max_span(rw) && lds <= 160 * 1024) {
             dim3 grid(a.N / a.unit_tn, (a.U + 8 * rw - 1) / (8 * rw), a.B);
             if (a.w2_units) {     // fused residual unit: one output block holds every channel, dense tensors, distinct output
-                if (a.unit_tn != 96 || a.taps != 7 || a.N != 96 || a.Cin != 96 || a.Cout != 96 || !a.alpha2 || !a.bias2 || a.res || a.in_bs ||
+                if (a.taps != 7 || a.N != a.unit_tn || a.Cin != a.unit_tn || a.Cout != a.unit_tn || !a.alpha2 || !a.bias2 || a.res || a.in_bs ||
                     a.out_bs || a.out == a.in || a.stride != 1 || a.act_out)
                     return hipErrorInvalidValue;
-                hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
+                if (a.unit_tn == 96) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
+                else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, true>), grid, dim3(512), lds, s, a);
                 return hipGetLastError();
             }
             if (a.unit_tn == 96) {
@@ -1172,7 +1222,8 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 else if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 2, RS, false>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 1, RS, false>), grid, dim3(512), lds, s, a);
             } else {
-                if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 2, RS, false>), grid, dim3(512), lds, s, a);
+                if (a.taps == 7) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, false>), grid, dim3(512), lds, s, a);
+                else if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 2, RS, false>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 1, RS, false>), grid, dim3(512), lds, s, a);
             }
             return hipGetLastError();

@@ -728,17 +728,17 @@ int load_dac_tensor(ptts_engine* e, const std::string& n, const float* data, con
             const size_t n = (size_t)taps * N * L.Cin;
             if (!L.w_hi) { PTTS_TRY(dev_alloc(e, &L.w_hi, n * 2)); PTTS_TRY(dev_alloc(e, &L.w_lo, n * 2)); }
             HIP_TRY(split_halves_launch(L.w, L.w_hi, L.w_lo, n, s));
-            // few-tap layers (transposed, 1x1) take 192-wide units where they divide N, everything else 96-wide ones
+            // 192-wide units (32 rows per wave) where they divide N: the staged window then serves twice the outputs; else 96-wide
             const bool no192 = getenv("PTTS_DAC_NO_UNIT192") != nullptr;      // A/B and the equivalence test
-            const int tn = (taps <= 2 && N % 192 == 0 && !no192) ? 192 : (N % 96 == 0 ? 96 : 0);
+            const int tn = (N % 192 == 0 && !no192) ? 192 : (N % 96 == 0 ? 96 : 0);
             if (tn) {
                 if (!L.w_units) PTTS_TRY(dev_alloc(e, &L.w_units, n * 4));
                 HIP_TRY(conv_units_launch(L.w_hi, L.w_lo, L.w_units, taps, N, L.Cin, tn, s));
                 L.unit_tn = tn;
             }
-            if (!L.transposed && L.k == 1 && L.Cin == 96 && L.Cout == 96) {
+            if (!L.transposed && L.k == 1 && L.Cin == L.Cout && (L.Cin == 96 || L.Cin == 192)) {
                 if (!L.w2_units) PTTS_TRY(dev_alloc(e, &L.w2_units, n * 4));
-                HIP_TRY(conv_units2_launch(L.w_hi, L.w_lo, L.w2_units, 96, s));
+                HIP_TRY(conv_units2_launch(L.w_hi, L.w_lo, L.w2_units, L.Cin, s));
             }
         }
         L.have_w = true;
@@ -1459,8 +1459,8 @@ int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, 
                 if (last) a.act_out = 1;
             }
             // residual unit whose channels fit one output block: conv7 -> snake -> conv1 -> + x in one launch (conv.h, w2_units)
-            if (fuse_units && !L.transposed && L.k == 7 && !last && L.unit_tn == 96 && L.Cin == 96 && L.Cout == 96 && 6 * L.dil <= 64 &&
-                e->dac[i + 1].k == 1 && e->dac[i + 1].w2_units) {
+            if (fuse_units && !L.transposed && L.k == 7 && !last && L.unit_tn == L.Cin && L.Cin == L.Cout && 6 * L.dil <= 64 &&
+                e->dac[i + 1].k == 1 && e->dac[i + 1].w2_units && e->dac[i + 1].Cin == L.Cout) {
                 const ConvLayer& L1 = e->dac[i + 1];
                 a.out = nxt; a.res = nullptr;
                 a.w2_units = L1.w2_units; a.bias2 = L1.bias; a.alpha2 = L1.alpha;

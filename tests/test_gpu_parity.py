@@ -739,9 +739,10 @@ def test_dac_ring_kernel_equals_the_tiled_kernel(hip):
 
 
 def test_dac_fused_residual_unit_equals_the_two_kernels(hip):
-    """C = 96 residual units run as ONE launch (7-tap conv tile kept in registers -> bias, Snake, fp16 split -> B operand of the 1x1
-    stage -> + x).  The 1x1 stage sums a k-step's 32 channels in the accumulator's channel order, so it agrees with the
-    two-kernel path to rounding (not bit for bit): the waveform has to stay within 2e-6 of it, 40 frames (edge masks) and 700."""
+    """C = 96 / 192 residual units run as ONE launch (7-tap conv tile kept in registers -> bias, Snake, fp16 split -> B operand of
+    the 1x1 stage -> + x; at C = 192 the 1x1 weights keep streaming through the ring).  The 1x1 stage sums a k-step's 32 channels
+    in the accumulator's channel order, so it agrees with the two-kernel path to rounding, not bit for bit: the waveform has to
+    stay within 1e-5 (max) / 1e-6 (rms) of it - a tenth of the fixture bound - at 40 frames (edge masks) and at 700."""
     from parler_tts_amd.modeling import DACModel
     from parler_tts_amd.weights import synthetic_state_dict
 
@@ -759,7 +760,8 @@ def test_dac_fused_residual_unit_equals_the_two_kernels(hip):
             finally:
                 del os.environ["PTTS_DAC_NO_FUSE"]
             assert float(ref.abs().max()) > 0.05
-            assert float((a - ref).abs().max()) < 2e-6, (shape, float((a - ref).abs().max()))
+            d = (a - ref).double()
+            assert float(d.abs().max()) < 1e-5 and float(d.pow(2).mean().sqrt()) < 1e-6, (shape, float(d.abs().max()))
     finally:
         del os.environ["PTTS_DAC_RING_MIN_U"]
 
