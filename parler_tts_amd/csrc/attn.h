@@ -28,6 +28,11 @@ struct AttnArgs {
     // folded QKV projection; the kernel finishes the LayerNorm of its head's three 64-wide slices (c1 / c2 are [3 D]), scales
     // q, and appends the k / v rows to the cache at state->pos itself before it streams the cache
     int lnfix_qkv = 0;       // 1: always use the general kernel (A/B and equivalence tests)
+    // decode, self-attention only: an utterance whose K codebook rows have all latched EOS only produces pad tokens from here on
+    // (select_kernel), whatever its logits are: its workgroups attend to key 0 alone instead of streaming the cache.  The
+    // reference keeps computing finished rows ("extension"); tokens and waveforms are unchanged.
+    const int* unfinished = nullptr;   // [B][alive_k] (select_kernel's latch), or null: never skip
+    int alive_k = 0, alive_b = 0;      // codebooks per utterance; utterances (query row r belongs to utterance r % alive_b: guidance halves)
     // batched prefill: query row r belongs to utterance r / rows_per_utt (its KV pages, its mask row); decode: 1
     int rows_per_utt = 1;
     // causal prefill kernel only: the launch covers positions pos0 .. pos0 + npos - 1 of every utterance; query row

@@ -70,7 +70,13 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     const int h = blockIdx.x, b = blockIdx.y;                    // b: query row; bu: the utterance whose cache it reads
     const int bu = b / a.rows_per_utt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int S = a.len_from_state ? (a.state->pos + 1) : a.len;
+    int S = a.len_from_state ? (a.state->pos + 1) : a.len;
+    if (a.unfinished) {                                           // finished utterance: one key instead of the whole cache
+        const int* u = a.unfinished + (bu % a.alive_b) * a.alive_k;
+        int alive = 0;
+        for (int k = 0; k < a.alive_k; ++k) alive |= u[k];
+        if (!alive) S = 1;
+    }
     const int tt = lane / LPT, c = lane % LPT;                    // token-in-tile, 16-byte chunk of the row
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
 

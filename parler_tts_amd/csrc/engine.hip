@@ -145,6 +145,7 @@ struct ptts_engine {
     int s_cap = 0;
     bool has_self_bias = false;
     int *tok_in = nullptr, *unfinished = nullptr;
+    bool skip_finished = true;          // PTTS_NO_SKIP_FINISHED=1: finished utterances keep streaming their cache (A/B, tests)
     long long* force = nullptr;
     bool use_force = false;
     const long long* force_seq = nullptr;   // ptts_set_forced_sequence
@@ -369,6 +370,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
         a.q = wk.q; a.ldq = D; a.pool = make_pool(e, false); a.layer = l; a.len_from_state = 1; a.state = e->state;
         a.bias = e->has_self_bias ? e->self_bias : nullptr; a.ld_bias = e->s_cap; a.s_cap = e->s_cap;
         a.ofrag = wk.attn_frag; a.D = D;
+        if (npos == 0 && e->skip_finished) { a.unfinished = e->unfinished; a.alive_k = c.codebooks; a.alive_b = e->B; }
         if (pre_qkv) {
             a.q = e->qkv_raw; a.ldq = 3 * D; a.lnfix_qkv = 1; a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16;
             a.lnfix_c1 = w.qkv_f.c1; a.lnfix_c2 = w.qkv_f.c2; a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
@@ -801,6 +803,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
     e->seq_prefill = getenv("PTTS_PREFILL_SEQ") != nullptr && atoi(getenv("PTTS_PREFILL_SEQ")) != 0;
     e->self_identity = getenv("PTTS_FORCE_PAGE_TABLE") == nullptr;     // A/B: always go through the table read
+    e->skip_finished = getenv("PTTS_NO_SKIP_FINISHED") == nullptr;
     if (const char* v = getenv("PTTS_PREFILL_CHUNK")) { e->pf_chunk = atoi(v); if (e->pf_chunk < 1) e->pf_chunk = 1; }
     if (cfg->dac_hidden > 0) {
         if (cfg->dac_n_up <= 0 || cfg->dac_n_up > 8 || cfg->dac_hidden % (16 << cfg->dac_n_up) != 0 || cfg->dac_latent % 16 != 0) {

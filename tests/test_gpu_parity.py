@@ -648,6 +648,59 @@ def test_generate_eos_paths(hip):
     assert wav.shape == ref.shape and float((wav - ref).pow(2).mean().sqrt()) < 1e-4
 
 
+def test_finished_utterances_stop_streaming_their_cache(hip):
+    """Extension of SURVEY 8f.2: once all K codebook rows of an utterance have latched EOS its self-attention reads one key instead
+    of the cache (every later token of it is pad whatever the logits say; the reference keeps computing such rows).  Ragged
+    finish by teacher forcing: utterance 1 of 3 gets EOS on every codebook at step 9, utterance 0 on ONE codebook only (it must
+    stay alive), utterance 2 runs free.  Raw ids, the loop state and the last logits of the live utterances must equal those of an
+    engine created with PTTS_NO_SKIP_FINISHED=1, in fp32 and bf16."""
+    from parler_tts_amd import _hip
+    from parler_tts_amd.delay_pattern import build_delay_pattern_mask
+
+    f, meta = load_case("tiny_greedy")
+    desc, amask, prompt, pmask = case_inputs(f)
+    enc = torch.from_numpy(f["enc_t5"])
+    for dtype in ("fp32", "bf16"):
+        outs = []
+        for skip in (True, False):
+            if not skip:
+                os.environ["PTTS_NO_SKIP_FINISHED"] = "1"
+            try:        # the switch is read when the engine is created: a model of its own per setting
+                from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+                cfg, sd = state_dict_for("tiny_greedy", meta, parts=("text_encoder", "decoder"))
+                model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=dtype, device="cuda:0")
+                K, B, L = cfg.decoder.num_codebooks, enc.shape[0], 48
+                eng = model.engine(B, enc.shape[1], prompt.shape[1], L)
+            finally:
+                os.environ.pop("PTTS_NO_SKIP_FINISHED", None)
+            dev = "cuda:0"
+            ids = torch.full((B * K, 1), cfg.decoder.bos_token_id, dtype=torch.long)
+            ids, pattern = build_delay_pattern_mask(ids, cfg.decoder.bos_token_id, cfg.decoder.pad_token_id, L, K)
+            pattern = pattern.to(dev).contiguous()
+            raw = torch.full((B * K, L), cfg.decoder.pad_token_id, dtype=torch.long, device=dev)
+            raw[:, :1] = ids.to(dev)
+            forced = torch.full((B * K, L), -1, dtype=torch.long, device=dev)
+            forced[K:2 * K, 9] = cfg.decoder.eos_token_id          # utterance 1: every codebook ends at column 9
+            forced[0, 9] = cfg.decoder.eos_token_id                # utterance 0: one codebook only
+            own = torch.full((B * K, L), -1, dtype=torch.long, device=dev)
+            eng.set_forced_sequence(forced, own)
+            try:
+                eng.prefill(B, B, enc.to(dev).contiguous(), amask.to(dev, torch.int32).contiguous(), prompt.to(dev).contiguous(),
+                            None if pmask is None else pmask.to(dev, torch.int32).contiguous(), pattern, raw, 1)
+                eng.decode_steps(L - 1, _hip.PttsSampling(0, 1.0, 0, 1.0, 0))
+                torch.cuda.synchronize()
+                st = eng.state()
+                outs.append((raw.cpu().clone(), eng.last_logits(B * K).cpu().clone(), st.cur_len, st.n_unfinished))
+            finally:
+                eng.set_forced_sequence(None)
+        (ra, la, ca, na), (rb, lb, cb, nb) = outs
+        B_, K_ = enc.shape[0], ra.shape[0] // enc.shape[0]
+        assert torch.equal(ra, rb) and ca == cb and na == nb
+        live = [r for r in range(ra.shape[0]) if not (K_ <= r < 2 * K_)]
+        assert torch.equal(la[live], lb[live]), dtype                 # live utterances: bit-identical logits
+        assert na == ra.shape[0] - K_ - 1                             # K rows of utterance 1 + one row of utterance 0 latched
+
+
 # ------------------------------------------------------------------------------------------------
 # codec: hand-written implicit-GEMM conv stack vs the fixtures of the structural oracle
 # ------------------------------------------------------------------------------------------------
