@@ -819,6 +819,27 @@ def test_dac_fused_residual_unit_equals_the_two_kernels(hip):
         del os.environ["PTTS_DAC_RING_MIN_U"]
 
 
+def test_dac_ring_kernels_relaunch_bit_identical(hip):
+    """The ring kernels order LDS-DMA against the MFMA waves with counted vmcnt waits and raw barriers: a wait that is one
+    instruction short shows up as a rare wrong tile, not as a parity failure.  60 relaunches of the whole decoder (ring, 192-wide
+    and fused kernels at every layer, 2 x 300 frames) must reproduce the first waveform bit for bit (`tools/dac_repeat.py` is the
+    longer form: 300 relaunches of 4 x 600 frames, 0 differences)."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
+    os.environ["PTTS_DAC_RING_MIN_U"] = "1"
+    try:
+        dac = DACModel(cfg, sd, device="cuda:0")
+        codes = torch.randint(0, 1024, (1, 2, 9, 300), generator=torch.Generator().manual_seed(5))
+        ref = dac.decode(codes, None).audio_values.clone()
+        bad = sum(0 if torch.equal(dac.decode(codes, None).audio_values, ref) else 1 for _ in range(60))
+        assert bad == 0 and float(ref.abs().max()) > 0.05
+    finally:
+        del os.environ["PTTS_DAC_RING_MIN_U"]
+
+
 def test_dac_decode_long_clip_chunked_equals_unchunked(hip):
     """time tiles, halos across tile seams and batch chunks: a long clip decoded alone must equal the same
     clip decoded inside a batch (size-independent property used at the BASELINE sizes)."""
