@@ -860,6 +860,34 @@ def test_dac_decode_long_clip_chunked_equals_unchunked(hip):
     assert torch.allclose(pre[..., : 300 * hop], full[..., : 300 * hop], atol=1e-6)
 
 
+def test_dac_decode_at_benchmark_length_properties(hip):
+    """BASELINE configs[1] codec shape (mini codec, F = 2571 frames = 1.3 M samples per clip; every layer on its production kernel:
+    LDS-DMA ring, 192-wide units, fused residual units, streaming 1x1, last-layer reduction).  No oracle finishes this size in
+    seconds, so size-independent properties: a clip decoded alone equals the same clip inside a batch (bit for bit: rows are
+    independent), the first 2000 frames of the long decode equal the decode of a 2100-frame prefix (locality: the receptive
+    field is ~10 frames) and agree with the register-staged two-kernel path (PTTS_DAC_NO_RING=1) to rounding."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
+    dac = DACModel(cfg, sd, device="cuda:0")
+    codes = torch.randint(0, 1024, (3, 9, 2571), generator=torch.Generator().manual_seed(2))
+    full = dac.decode(codes[None], [None]).audio_values
+    one = dac.decode(codes[1:2][None], [None]).audio_values
+    assert full.shape[-1] == 2571 * cfg.audio_encoder.hop_length and torch.equal(full[1:2], one)
+    pre = dac.decode(codes[:1, :, :2100][None], [None]).audio_values
+    hop = cfg.audio_encoder.hop_length
+    assert torch.allclose(pre[..., : 2000 * hop], full[:1, ..., : 2000 * hop], atol=1e-6)
+    os.environ["PTTS_DAC_NO_RING"] = "1"
+    try:
+        ref = dac.decode(codes[:1][None], [None]).audio_values
+    finally:
+        del os.environ["PTTS_DAC_NO_RING"]
+    d = (full[:1] - ref).double()
+    assert float(d.abs().max()) < 1e-5 and float(d.pow(2).mean().sqrt()) < 1e-6 and float(ref.abs().max()) > 0.05
+
+
 # ------------------------------------------------------------------------------------------------
 # codec, encode direction (audio prompts): DAC encoder conv stack + residual vector quantiser
 # ------------------------------------------------------------------------------------------------
