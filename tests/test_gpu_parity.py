@@ -819,6 +819,32 @@ def test_dac_fused_residual_unit_equals_the_two_kernels(hip):
         del os.environ["PTTS_DAC_RING_MIN_U"]
 
 
+@pytest.mark.parametrize("B,F", [(1, 1), (3, 2), (1, 7), (2, 33), (1, 257)])
+def test_dac_odd_shapes_on_the_ring_and_fused_kernels(hip, B, F):
+    """Edge shapes (one frame, fewer rows than a 16-row tile, lengths that leave partial tiles in every layer): the ring kernel
+    at every wide layer (PTTS_DAC_RING_MIN_U=1) and the fused residual units against the register-staged two-kernel path."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
+    dac = DACModel(cfg, sd, device="cuda:0")
+    codes = torch.randint(0, 1024, (1, B, 9, F), generator=torch.Generator().manual_seed(100 * B + F))
+    os.environ["PTTS_DAC_RING_MIN_U"] = "1"
+    try:
+        a = dac.decode(codes, None).audio_values.cpu()
+    finally:
+        del os.environ["PTTS_DAC_RING_MIN_U"]
+    os.environ["PTTS_DAC_NO_RING"] = "1"
+    try:
+        ref = dac.decode(codes, None).audio_values.cpu()
+    finally:
+        del os.environ["PTTS_DAC_NO_RING"]
+    assert a.shape == ref.shape == (B, 1, F * cfg.audio_encoder.hop_length) and bool(torch.isfinite(a).all())
+    d = (a - ref).double()
+    assert float(d.abs().max()) < 1e-5 and float(d.pow(2).mean().sqrt()) < 1e-6
+
+
 def test_dac_ring_kernels_relaunch_bit_identical(hip):
     """The ring kernels order LDS-DMA against the MFMA waves with counted vmcnt waits and raw barriers: a wait that is one
     instruction short shows up as a rare wrong tile, not as a parity failure.  60 relaunches of the whole decoder (ring, 192-wide
