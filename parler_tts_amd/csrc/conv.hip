@@ -763,6 +763,162 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_kernel_s1: wide 1x1 convs (C = 384 / 768 residual units) without an activation window.
+//
+// On conv_kernel_h3r a 1x1 layer spends a chunk's 7.7 k cycles as 2.3 k of matrix-pipe work, 2.1 k of Snake / split / LDS writes
+// and 3.3 k of barriers and waits around them: one tap per staged window.  A 1x1 conv has no halo, so nothing is shared between
+// waves but the weights: every wave loads ITS 32 rows x 32 channels straight into MFMA B-fragment order (lane = (channel group g,
+// row t): 8 consecutive channels = 32 contiguous bytes, the four groups of a row one 128-byte line), two chunks ahead in two
+// register sets, applies Snake + the fp16 split in registers while the other wave of its SIMD multiplies, and the weight units
+// travel through the LDS-DMA ring as before.  One barrier per chunk (the ring's), no LDS traffic for activations.  The fragments
+// of chunk c + 1 are prepared BEHIND the MFMAs of chunk c: the plain loads they need were issued a whole MFMA phase earlier, so
+// the vmcnt drain hipcc puts in front of them (it does not count LDS-DMA exactly) finds everything landed.
+// Same products in the same order as conv_kernel_h3: bit-identical.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv_kernel_s1(ConvArgs a) {
+    constexpr int TN = 192, NT = TN / 16, NI = 2, RW = 32, TMW = 8 * RW, RS = 4, D = 3, UB = TN * 128, G = UB / 8192;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                            // [RS][hi: TN x 64 B | lo: TN x 64 B]
+    float* als = reinterpret_cast<float*>(smem + RS * UB);        // [Cin] Snake alpha, [Cin] 1 / (alpha + 1e-9)
+    float* ivs = als + a.Cin;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, t16 = lane & 15;
+    // (an XCD-aware block map that puts the output blocks of one row tile on one XCD, so that the rows come from HBM once, measured
+    // slower: 1.73 vs 1.62 ms at C = 768 - each XCD then cycles through all the layer's weight units instead of one block's)
+    const int nb = blockIdx.x;
+    const int n0 = nb * TN;
+    const int u0 = blockIdx.y * TMW;
+    const int b = blockIdx.z;
+    const int nchunks = a.Cin / KC3;
+    const bool snake = a.alpha != nullptr;
+    const char* units = reinterpret_cast<const char*>(a.w_units) + (size_t)nb * nchunks * UB;
+    const float* inb = a.in + (size_t)b * a.Tin * a.Cin;
+
+    auto dma = [&](int u) {                               // unit (= chunk) u into slot u % RS; past the end: the last one again
+        const int uc = u < nchunks ? u : nchunks - 1;
+        const char* src = units + (size_t)uc * UB + (size_t)tid * 16;
+        char* dst = ring + (u % RS) * UB + w * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src + j * 8192), (lds_void*)(dst + j * 8192), 16, 0, 0);
+#else
+        (void)src; (void)dst;
+#endif
+    };
+    // the lane's two rows (clamped: rows past the end are computed on the last row and never stored)
+    const float* xrow[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int u = u0 + w * RW + i * 16 + t16;
+        if (u > a.Tin - 1) u = a.Tin - 1;
+        xrow[i] = inb + (size_t)u * a.Cin + 8 * g;
+    }
+    float4 xs[2][NI][2];                                   // [register set][row tile][two float4 = 8 channels]
+    auto xload = [&](auto setc, int c) {
+        constexpr int S = decltype(setc)::value;
+        const int cc = c < nchunks ? c : nchunks - 1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            xs[S][i][0] = *reinterpret_cast<const float4*>(xrow[i] + cc * KC3);
+            xs[S][i][1] = *reinterpret_cast<const float4*>(xrow[i] + cc * KC3 + 4);
+        }
+    };
+    half8 fh[NI], fl[NI];                                  // B fragments of the chunk about to be multiplied
+    auto prepare = [&](auto setc, int c) {                 // Snake + split of chunk c (register set S) into fh / fl
+        constexpr int S = decltype(setc)::value;
+        const int cc = c < nchunks ? c : nchunks - 1;
+        f32x4 al0 = {0, 0, 0, 0}, al1 = {0, 0, 0, 0}, iv0 = {0, 0, 0, 0}, iv1 = {0, 0, 0, 0};
+        if (snake) {
+            al0 = *reinterpret_cast<const f32x4*>(als + cc * KC3 + 8 * g); al1 = *reinterpret_cast<const f32x4*>(als + cc * KC3 + 8 * g + 4);
+            iv0 = *reinterpret_cast<const f32x4*>(ivs + cc * KC3 + 8 * g); iv1 = *reinterpret_cast<const f32x4*>(ivs + cc * KC3 + 8 * g + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float x8[8] = {xs[S][i][0].x, xs[S][i][0].y, xs[S][i][0].z, xs[S][i][0].w,
+                                 xs[S][i][1].x, xs[S][i][1].y, xs[S][i][1].z, xs[S][i][1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = snake ? snake_f(x8[e], e < 4 ? al0[e] : al1[e - 4], e < 4 ? iv0[e] : iv1[e - 4]) : x8[e];
+                _Float16 h, l;
+                split_h(y, h, l);
+                fh[i][e] = h;
+                fl[i][e] = l;
+            }
+        }
+    };
+
+    f32x4 acc[NI][NT];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = {0, 0, 0, 0};
+
+    // prologue: Snake table, chunk 0 prepared, chunk 1 in flight, units 0 .. D - 1 in flight
+    if (snake)
+        for (int i = tid; i < a.Cin; i += 512) { const float al = a.alpha[i]; als[i] = al; ivs[i] = 1.0f / (al + 1e-9f); }
+    xload(std::integral_constant<int, 0>{}, 0);
+    xload(std::integral_constant<int, 1>{}, 1);
+    lds_barrier();                                        // the table
+    prepare(std::integral_constant<int, 0>{}, 0);
+#pragma unroll
+    for (int v = 0; v < D; ++v) dma(v);
+
+    int slot = 0;
+    auto step = [&](int c, auto parc) {
+        constexpr int P = decltype(parc)::value;           // c % 2: chunk c was loaded into set P, chunk c + 1 sits in set 1 - P
+        if (c < D) wait_vmcnt<G * (D - 1)>();             // own pieces of unit c landed (a lower bound on the younger operations)
+        else wait_vmcnt<G * (D - 1)>();
+        lds_barrier();                                    // everyone's pieces of unit c are in LDS, everyone is done reading unit c - 1
+        dma(c + D);
+        xload(std::integral_constant<int, P>{}, c + 2);   // set P is free: chunk c is in fh / fl
+        asm volatile("" ::: "memory");
+        const _Float16* wh = reinterpret_cast<const _Float16*>(ring + slot * UB);
+        const _Float16* wl = wh + TN * LDH;
+        const size_t wo = (size_t)t16 * LDH + 8 * swz16(t16, g);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const half8 bh = *reinterpret_cast<const half8*>(wh + wo + (size_t)j * 16 * LDH);
+            const half8 bl = *reinterpret_cast<const half8*>(wl + wo + (size_t)j * 16 * LDH);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {                // small terms first, then the leading term
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, fh[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, fl[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, fh[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (++slot == RS) slot = 0;
+        prepare(std::integral_constant<int, 1 - P>{}, c + 1);     // behind the MFMAs: the next chunk's fragments
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        step(c, std::integral_constant<int, 0>{});
+        if (c + 1 < nchunks) step(c + 1, std::integral_constant<int, 1>{});
+    }
+    wait_vmcnt<0>();
+
+    const size_t obs = (size_t)a.Tout * a.Cout;
+    float* outb = a.out + (size_t)b * obs;
+    const float* resb = a.res ? a.res + (size_t)b * obs : nullptr;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int u = u0 + w * RW + i * 16 + t16;
+        if (u >= a.U) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + j * 16 + 4 * g;
+            const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
+            float4 y = make_float4(acc[i][j][0] + bs.x, acc[i][j][1] + bs.y, acc[i][j][2] + bs.z, acc[i][j][3] + bs.w);
+            if (resb) {
+                const float4 rv = *reinterpret_cast<const float4*>(resb + (size_t)u * a.Cout + co);
+                y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
+            }
+            *reinterpret_cast<float4*>(outb + (size_t)u * a.Cout + co) = y;
+        }
+    }
+}
+
 // A fragments of a fused 1x1 stage (C -> C): unit m = k-step m: { hi: [C / 16 blocks][64 lanes] x 16 B, lo: same }; lane (g = l >> 4,
 // n = l & 15) of block jb holds W[16 jb + n][channel of k position 8 g + e], e = 0 .. 7, with the accumulator's channel order
 // channel = 32 m + 4 g + e (e < 4), 32 m + 16 + 4 g + (e - 4) (e >= 4)
@@ -1118,6 +1274,8 @@ hipError_t conv_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 1, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_s1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1215,6 +1373,13 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                     return hipErrorInvalidValue;
                 if (a.unit_tn == 96) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, true>), grid, dim3(512), lds, s, a);
+                return hipGetLastError();
+            }
+            if (a.unit_tn == 192 && a.taps == 1 && a.stride == 1 && !a.in_bs && !a.out_bs && a.act_out == 0 && a.Tin == a.Tout &&
+                a.U == a.Tout && a.Cin <= 2048 && getenv("PTTS_DAC_NO_S1") == nullptr) {
+                // wide 1x1 conv: activations straight into B fragments, no window
+                const size_t lds_s1 = (size_t)4 * 192 * 128 + (size_t)2 * a.Cin * sizeof(float);
+                hipLaunchKernelGGL(conv_kernel_s1, grid, dim3(512), lds_s1, s, a);
                 return hipGetLastError();
             }
             if (a.unit_tn == 96) {
