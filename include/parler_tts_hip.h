@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 6
+#define PTTS_ABI_VERSION 7
 
 enum { PTTS_DTYPE_F32 = 0, PTTS_DTYPE_BF16 = 1 };
 
@@ -210,6 +210,15 @@ int ptts_set_forced_sequence(ptts_engine* e, const int64_t* forced_ids, int64_t*
  * "codec_latent" = the encoder output [b][F][latent] of the last ptts_dac_encode chunk). */
 int ptts_debug_stop_after(ptts_engine* e, int32_t n_kernels);
 int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* bytes);
+
+/* Test hook: how many conv launches of the codec (ptts_dac_decode / ptts_dac_encode, any engine of this process) went to each
+ * kernel family since the last reset, so that a parity test at production size can assert that the production kernels -
+ * not a fallback - produced the waveform it compared.  counts_host[i], i < n:
+ *   0 conv_last_kernel  1 / 2 conv1x1_stream_kernel<96 / 192>  3 / 4 fused residual unit (conv_kernel_h3r<.., true>) 96 / 192 wide
+ *   5 conv_kernel_s1  6 / 7 / 8 conv_kernel_h3r<96, 64, taps 7 / 2 (transposed) / 1>  9 / 10 / 11 conv_kernel_h3r<192, 32, taps 7 / 2 / 1>
+ *   12 conv_kernel_h3 (register-staged)  13 conv_kernel (fp32 MFMA).   PTTS_DAC_KERNEL_KINDS entries exist. */
+#define PTTS_DAC_KERNEL_KINDS 14
+int ptts_dac_kernel_counts(int64_t* counts_host, int32_t n, int32_t reset);
 
 /* HIP-event profile of the dominant kernel (self-attention decode): sums over the sampled launches. */
 typedef struct ptts_profile {

@@ -145,6 +145,76 @@ def dac_cases():
         save(name, codes=codes, latent=z, wav=wav, seed=seed)
 
 
+def _sparse_wave(wav, stride=64, block=4096, windows=()):
+    """what is kept of a waveform too long to store whole: every ``stride``-th sample, float64 sums over
+    ``block``-sample blocks (a checksum of every sample), and a few whole windows"""
+    w = wav.detach().double().reshape(wav.shape[0], -1)
+    n = w.shape[1]
+    nb = (n + block - 1) // block
+    pad = torch.zeros(w.shape[0], nb * block - n, dtype=w.dtype)
+    sums = torch.cat([w, pad], 1).reshape(w.shape[0], nb, block).sum(-1)
+    sq = torch.cat([w * w, pad], 1).reshape(w.shape[0], nb, block).sum(-1)
+    out = dict(wav_stride=wav.reshape(wav.shape[0], -1)[:, ::stride].float(), stride=stride, block=block,
+               block_sums=sums, block_sqsums=sq, n_samples=n)
+    for i, (a, b) in enumerate(windows):
+        out[f"win{i}"] = wav.reshape(wav.shape[0], -1)[:, a:b].float()
+        out[f"win{i}_range"] = np.array([a, b])
+    out["n_windows"] = len(windows)
+    return out
+
+
+def dac_long_cases():
+    """Codec decode / encode at sizes where the PRODUCTION kernels are selected: the ring, fused,
+    windowless and last-layer kernels of conv.hip only run from 1024 output rows per utterance upwards, which the 6-frame
+    dac_mini fixture never reaches.  Same structural oracle (installed transformers DacModel with the engine's weights):
+    (a) B = 2, F = 300: whole waveform; (b) B = 1, F = 2571 (the benchmark clip): every 64th sample, float64 block sums of
+    every sample, and whole windows at the head, across tile seams in the middle and at the tail;
+    (c) encode of 1.2 s of audio (B = 2), codes + latent."""
+    from parler_tts_amd.weights import synthetic_dac_encoder_state_dict
+
+    mini = mini_v01_config()
+    sd = synthetic_state_dict(mini, seed=21, parts=("audio_encoder",))
+    hf = ref_shim.build_hf_dac(mini, sd)
+    K, V = mini.audio_encoder.num_codebooks, mini.audio_encoder.codebook_size
+    hop = int(np.prod(mini.audio_encoder.upsampling_ratios))
+    for name, B, Fr, seed_c in (("dac_mini_f300", 2, 300, 6), ("dac_mini_f2571", 1, 2571, 7)):
+        gg = torch.Generator().manual_seed(seed_c)
+        codes = torch.randint(0, V, (B, K, Fr), generator=gg)
+        with torch.no_grad():
+            z = hf.quantizer.from_codes(codes)[0]
+            wav = hf.decoder(z)
+        print(f"  {name}: wav {tuple(wav.shape)} rms {float(wav.pow(2).mean().sqrt()):.4f}")
+        if Fr <= 300:
+            save(name, codes=codes, wav=wav, seed=21)
+        else:
+            n = Fr * hop
+            wins = [(0, 8192), (n // 2 - 4096, n // 2 + 4096), (1000 * hop - 2048, 1000 * hop + 2048), (n - 8192, n)]
+            save(name, codes=codes, seed=21, **_sparse_wave(wav, windows=wins))
+    # ---- (c) encode
+    sd_c = synthetic_state_dict(mini, seed=23, parts=("audio_encoder",))
+    sd_c.update(synthetic_dac_encoder_state_dict(mini.audio_encoder, seed=23))
+    hf_e = ref_shim.build_hf_dac(mini, sd_c)
+    B, T = 2, 512 * 103 + 77          # 1.2 s at 44.1 kHz, not a hop multiple
+    for seed_in in range(300, 400):
+        gg = torch.Generator().manual_seed(seed_in)
+        audio = (torch.rand(B, 1, T, generator=gg) * 2 - 1) * 0.5
+        ms = []
+        z = cpu_ref.dac_encoder(mini, sd_c, audio)
+        codes = cpu_ref.dac_quantize(mini, sd_c, z, margins=ms)
+        if min(ms) >= 1e-4:
+            break
+        print(f"  dac_enc_mini_long: seed_in={seed_in} min gap {min(ms):.2e}, next")
+    else:
+        raise RuntimeError("no seed met the margin")
+    with torch.no_grad():
+        hc = hf_e.encode(audio).audio_codes
+    assert torch.equal(hc, codes), "oracle dac_encode differs from transformers DacModel.encode"
+    print(f"  dac_enc_mini_long: seed_in={seed_in} min top-2 distance gap {min(ms):.2e}, codes {tuple(codes.shape)}")
+    # the audio is re-created from seed_in by the test (rand of a torch CPU generator is platform independent)
+    save("dac_enc_mini_long", codes=codes[None, ...], latent=z[:, :, ::4].contiguous(), latent_stride=4, seed=23, seed_in=seed_in,
+         B=B, T=T, min_margin=min(ms))
+
+
 def dac_encode_cases():
     """codec ENCODE (audio prompts, D:25-96) vs the installed transformers DacModel.encode; the input seed is scanned until
     every nearest-codebook-entry decision has a top-2 distance gap >= 1e-4, so that bit-exact codes are a fair demand on an
@@ -244,18 +314,31 @@ def long_cases():
     kwm = dict(seed=21, never_eos=True, ln_jitter=0.0)
     L = 512
     steps = {0, 1, 57, 58, 121, 249, 250, 377, 441} | set(range(L - 7, L - 1))
-    run_case("minilong_greedy", mini, kwm, B=2, T=12, P=6, L=L, seed_in=11300, record=frozenset(steps))
+    if "--skip-512" not in sys.argv:
+        run_case("minilong_greedy", mini, kwm, B=2, T=12, P=6, L=L, seed_in=11300, record=frozenset(steps))
 
 
-def bf16_long_case():
+def long2580_case():
+    """The exact BASELINE configs[1] shape at its full horizon: mini_v0.1 dimensions (24 x 1024, 16 heads),
+    max_length 2580, the REAL reference forward with its cat-grown KV.  Logits at every KV page boundary the run crosses
+    (P = 6: a new page starts at step 58 + 64 i), at S > 1024 and S > 2048 and over the last 8 steps; the top-2 margin of
+    every one of the 2579 x 18 argmaxes."""
+    mini = mini_v01_config()
+    kwm = dict(seed=21, never_eos=True, ln_jitter=0.0)
+    L = 2580
+    steps = {0, 1} | set(range(58, L - 1, 64)) | {57, 1023, 1024, 1025, 2047, 2048, 2049} | set(range(L - 9, L - 1))
+    run_case("minilong2580_greedy", mini, kwm, B=2, T=12, P=6, L=L, seed_in=11300, record=frozenset(steps))
+
+
+def bf16_long_case(name="minilong_greedy"):
     """The engine-numerics (bf16 mode) restatement, oracle/cpu_ref_bf16.py, teacher-forced along the REFERENCE's raw ids of
     minilong_greedy (512 columns at mini_v0.1 size are minutes of CPU, too slow for the GPU box's test run): logits of the
     same sampled steps, its own argmax of every step and the top-2 margin of those argmaxes.  Does not need /root/reference."""
     from oracle import cpu_ref_bf16
     from tests.helpers import case_inputs, load_case, state_dict_for
 
-    f, meta = load_case("minilong_greedy")
-    cfg, sd = state_dict_for("minilong_greedy", meta)
+    f, meta = load_case(name)
+    cfg, sd = state_dict_for(name, meta)
     desc, amask, prompt, pmask = case_inputs(f)
     steps = set(int(x) for x in f["logit_steps"])
     gold = torch.from_numpy(f["raw_ids"])
@@ -282,8 +365,14 @@ def bf16_long_case():
         del dec
     # the second evaluation accumulates every product and statistic in fp64: the distance between the two is the
     # restatement's own re-association spread, the yardstick of the bf16 GPU test
-    print("  re-association spread of the restatement:", float((out["step_logits"] - out["step_logits_acc64"]).abs().max()))
-    save("minilong_greedy_bf16", **out)
+    spread = (out["step_logits"] - out["step_logits_acc64"]).abs()
+    print("  re-association spread of the restatement:", float(spread.max()))
+    if name != "minilong_greedy":
+        # long fixtures keep the spread (per sampled step) instead of the second copy of the logits
+        out["spread_per_step"] = spread.reshape(spread.shape[0], -1).max(1)[0]
+        out["spread"] = spread.max()
+        del out["step_logits_acc64"]
+    save(name + "_bf16", **out)
 
 
 def nrs_case():
@@ -341,6 +430,18 @@ def main():
     if "--only-bf16" in sys.argv:
         torch.set_num_threads(8)
         bf16_long_case()
+        return
+    if "--only-long2580" in sys.argv:
+        torch.set_num_threads(8)
+        long2580_case()
+        return
+    if "--only-bf16-2580" in sys.argv:
+        torch.set_num_threads(8)
+        bf16_long_case("minilong2580_greedy")
+        return
+    if "--only-dac-long" in sys.argv:
+        torch.set_num_threads(8)
+        dac_long_cases()
         return
     if "--only-nrs" in sys.argv:
         nrs_case()

@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libparler_tts_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 # every symbol include/parler_tts_hip.h declares (tests check the export table against this list)
@@ -19,8 +19,12 @@ EXPORTS = [
     "ptts_last_error", "ptts_abi_version", "ptts_create", "ptts_destroy", "ptts_load_tensor", "ptts_weights_ready",
     "ptts_t5_encode", "ptts_dac_decode", "ptts_dac_encode", "ptts_set_prompt_embeds", "ptts_set_decoder_mask", "ptts_prefill", "ptts_decode_steps", "ptts_forward_step", "ptts_select_step", "ptts_get_state", "ptts_last_logits",
     "ptts_set_block_table", "ptts_pool_info", "ptts_set_forced_tokens", "ptts_set_forced_sequence", "ptts_profile_read", "ptts_test_gemm",
-    "ptts_debug_stop_after", "ptts_debug_buffer",
+    "ptts_debug_stop_after", "ptts_debug_buffer", "ptts_dac_kernel_counts",
 ]
+
+# kernel families of ptts_dac_kernel_counts (include/parler_tts_hip.h)
+DAC_KERNEL_KINDS = ["last", "stream96", "stream192", "fused96", "fused192", "s1", "ring96_t7", "ring96_t2", "ring96_t1",
+                    "ring192_t7", "ring192_t2", "ring192_t1", "h3", "f32"]
 
 
 class PttsConfig(C.Structure):
@@ -105,6 +109,7 @@ def load_library() -> C.CDLL:
     lib.ptts_profile_read.argtypes = [vp, C.POINTER(PttsProfile), i32]
     lib.ptts_debug_stop_after.argtypes = [vp, i32]
     lib.ptts_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.ptts_dac_kernel_counts.argtypes = [i64p, i32, i32]
     lib.ptts_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, i32, vp, vp, C.c_float, i32, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ptts_last_error",):
@@ -114,6 +119,14 @@ def load_library() -> C.CDLL:
         raise RuntimeError(f"{LIB_PATH}: ABI version {lib.ptts_abi_version()} != binding {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
+
+
+def dac_kernel_counts(reset: bool = False) -> dict:
+    """launches per codec conv kernel family since the last reset (test hook)"""
+    lib = load_library()
+    buf = (C.c_int64 * len(DAC_KERNEL_KINDS))()
+    check(lib.ptts_dac_kernel_counts(buf, len(DAC_KERNEL_KINDS), 1 if reset else 0))
+    return {k: int(buf[i]) for i, k in enumerate(DAC_KERNEL_KINDS)}
 
 
 class PttsError(RuntimeError):

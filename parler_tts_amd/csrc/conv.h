@@ -27,6 +27,26 @@ struct ConvArgs {
     size_t in_bs = 0, out_bs = 0;  // floats between utterances of in / out (and res); 0 = dense (Tin*Cin, Tout*Cout)
 };
 
+// kernel families conv_launch dispatches to (indices of ptts_dac_kernel_counts, include/parler_tts_hip.h)
+enum {
+    CONV_KIND_LAST = 0,        // conv_last_kernel (one output channel)
+    CONV_KIND_STREAM_96 = 1,   // conv1x1_stream_kernel<96>
+    CONV_KIND_STREAM_192 = 2,  // conv1x1_stream_kernel<192>
+    CONV_KIND_FUSED_96 = 3,    // conv_kernel_h3r<96, 64, 7, 4, true>   fused residual unit
+    CONV_KIND_FUSED_192 = 4,   // conv_kernel_h3r<192, 32, 7, 4, true>
+    CONV_KIND_S1 = 5,          // conv_kernel_s1 (windowless wide 1x1)
+    CONV_KIND_RING_96_T7 = 6,  // conv_kernel_h3r<96, 64, 7 | 2 | 1, 4, false>: 6, 7 (transposed), 8
+    CONV_KIND_RING_96_T2 = 7,
+    CONV_KIND_RING_96_T1 = 8,
+    CONV_KIND_RING_192_T7 = 9, // conv_kernel_h3r<192, 32, 7 | 2 | 1, 4, false>: 9, 10 (transposed), 11
+    CONV_KIND_RING_192_T2 = 10,
+    CONV_KIND_RING_192_T1 = 11,
+    CONV_KIND_H3 = 12,         // conv_kernel_h3 (register-staged fp16 x3 kernel)
+    CONV_KIND_F32 = 13,        // conv_kernel (fp32 MFMA)
+    CONV_KIND_COUNT = 14
+};
+void conv_kernel_counts(long long* out, int n, bool reset);
+
 hipError_t conv_init();
 hipError_t conv_launch(const ConvArgs& a, hipStream_t s);
 hipError_t dac_latent_launch(const long long* codes, const float* table, float* z, int B, int K, int F, int C, int ncodes,

@@ -27,6 +27,7 @@
 // while they are staged (after Snake).  256 time rows x TN outputs per 8-wave workgroup, 32-channel chunks.
 #include "ptts_common.h"
 #include "conv.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -1300,6 +1301,16 @@ size_t conv_h3_lds(const ConvArgs& a, int TN, int RW = 32) {
     return ((size_t)2 * win * LDH + (size_t)2 * a.taps * TN * LDH) * sizeof(_Float16);
 }
 
+// which kernel each conv_launch call dispatched (host-side tallies: tests assert that a decode at production size ran on
+// the production kernels and not on a fallback; include/parler_tts_hip.h: ptts_dac_kernel_counts)
+static std::atomic<long long> g_conv_counts[CONV_KIND_COUNT];
+static inline void tally(int kind) { g_conv_counts[kind].fetch_add(1, std::memory_order_relaxed); }
+void conv_kernel_counts(long long* out, int n, bool reset) {
+    for (int i = 0; i < n && i < CONV_KIND_COUNT; ++i) out[i] = g_conv_counts[i].load(std::memory_order_relaxed);
+    for (int i = CONV_KIND_COUNT; i < n; ++i) out[i] = 0;
+    if (reset) for (int i = 0; i < CONV_KIND_COUNT; ++i) g_conv_counts[i].store(0, std::memory_order_relaxed);
+}
+
 #ifdef PTTS_CONV_STAMPS
 static hipError_t conv_launch_inner(const ConvArgs& a, hipStream_t s);
 hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
@@ -1328,6 +1339,7 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     if (getenv("PTTS_DAC_NO_LAST_KERNEL") == nullptr && a.Cout == 1 && a.N == 1 && a.taps == 7 && a.tstep == 1 && a.toff == -3 &&
         a.stride == 1 && a.Cin % 32 == 0 && a.alpha && !a.res && a.Tin == a.Tout) {
         hipLaunchKernelGGL(conv_last_kernel, dim3((a.Tout + 255) / 256, a.B), dim3(256), 0, s, a);
+        tally(CONV_KIND_LAST);
         return hipGetLastError();
     }
     // residual 1x1 conv of the narrow, long blocks: the streaming kernel (dense rows, Snake on the input, residual add)
@@ -1340,6 +1352,7 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
             const size_t lds = (size_t)6 * 3 * 64 * 16 * 2 + 2 * 96 * sizeof(float);
             long long g = (tiles + 3) / 4; if (g > 256 * 4) g = 256 * 4;
             hipLaunchKernelGGL((conv1x1_stream_kernel<96, 4>), dim3((unsigned)g), dim3(256), lds, s, a, rows);
+            tally(CONV_KIND_STREAM_96);
         } else {
             const size_t lds = (size_t)12 * 6 * 64 * 16 * 2 + 2 * 192 * sizeof(float);
             if (getenv("PTTS_DAC_1X1_WAVES8")) {
@@ -1349,6 +1362,7 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 long long g = (tiles + 15) / 16; if (g > 256) g = 256;
                 hipLaunchKernelGGL((conv1x1_stream_kernel<192, 16>), dim3((unsigned)g), dim3(1024), lds, s, a, rows);
             }
+            tally(CONV_KIND_STREAM_192);
         }
         return hipGetLastError();
     }
@@ -1373,6 +1387,7 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                     return hipErrorInvalidValue;
                 if (a.unit_tn == 96) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, true>), grid, dim3(512), lds, s, a);
+                tally(a.unit_tn == 96 ? CONV_KIND_FUSED_96 : CONV_KIND_FUSED_192);
                 return hipGetLastError();
             }
             if (a.unit_tn == 192 && a.taps == 1 && a.stride == 1 && !a.in_bs && !a.out_bs && a.act_out == 0 && a.Tin == a.Tout &&
@@ -1380,6 +1395,7 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 // wide 1x1 conv: activations straight into B fragments, no window
                 const size_t lds_s1 = (size_t)4 * 192 * 128 + (size_t)2 * a.Cin * sizeof(float);
                 hipLaunchKernelGGL(conv_kernel_s1, grid, dim3(512), lds_s1, s, a);
+                tally(CONV_KIND_S1);
                 return hipGetLastError();
             }
             if (a.unit_tn == 96) {
@@ -1391,9 +1407,13 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 else if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 2, RS, false>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 1, RS, false>), grid, dim3(512), lds, s, a);
             }
+            tally((a.unit_tn == 96 ? CONV_KIND_RING_96_T7 : CONV_KIND_RING_192_T7) + (a.taps == 7 ? 0 : (a.taps == 2 ? 1 : 2)));
             return hipGetLastError();
         }
     }
+    // the fused residual unit exists on the ring kernel only: a guard above that failed must not fall through to a kernel
+    // that would silently drop the unit's 1x1 conv and residual
+    if (a.w2_units) return hipErrorInvalidValue;
     if (a.w_hi && a.w_lo && a.Cin % KC3 == 0) {
         // TN = 96 when it divides N and fits LDS, else 64
         int TN = (a.N % 96 == 0 && conv_h3_lds(a, 96) <= 160 * 1024) ? 96 : 64;
@@ -1418,6 +1438,7 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
             else if (TN == 96 && RW == 32) hipLaunchKernelGGL((conv_kernel_h3<96, 32>), grid, dim3(512), lds3, s, a);
             else if (TN == 64) hipLaunchKernelGGL((conv_kernel_h3<64, 64>), grid, dim3(512), lds3, s, a);
             else hipLaunchKernelGGL((conv_kernel_h3<96, 64>), grid, dim3(512), lds3, s, a);
+            tally(CONV_KIND_H3);
             return hipGetLastError();
         }
     }
@@ -1430,6 +1451,7 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.N + TN - 1) / TN, (a.U + TM - 1) / TM, a.B);
     if (TN == 64) hipLaunchKernelGGL(conv_kernel<64>, grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL(conv_kernel<96>, grid, dim3(256), lds, s, a);
+    tally(CONV_KIND_F32);
     return hipGetLastError();
 }
 

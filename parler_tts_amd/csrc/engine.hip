@@ -1603,6 +1603,14 @@ int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* byt
     return PTTS_OK;
 }
 
+int ptts_dac_kernel_counts(int64_t* counts_host, int32_t n, int32_t reset) {
+    if (!counts_host || n <= 0) return fail(PTTS_E_INVALID, "ptts_dac_kernel_counts: no output");
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64_t is long long here");
+    static_assert(CONV_KIND_COUNT == PTTS_DAC_KERNEL_KINDS, "header and conv.h disagree on the kernel families");
+    conv_kernel_counts(reinterpret_cast<long long*>(counts_host), n, reset != 0);
+    return PTTS_OK;
+}
+
 int ptts_profile_read(ptts_engine* e, ptts_profile* out, int32_t reset) {
     if (!e || !out) return fail(PTTS_E_INVALID, "null argument");
     HIP_TRY(hipDeviceSynchronize());

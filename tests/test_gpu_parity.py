@@ -914,6 +914,64 @@ def test_dac_decode_at_benchmark_length_properties(hip):
     assert float(d.abs().max()) < 1e-5 and float(d.pow(2).mean().sqrt()) < 1e-6 and float(ref.abs().max()) > 0.05
 
 
+
+def _production_kernel_counts(frames_ge_1024):
+    """launches per kernel family of ONE mini-codec decode in the default environment (conv.hip dispatch): conv0 and the
+    first transposed conv have F and F + 1 GEMM rows, so below 1024 frames those two stay on the register-staged kernel"""
+    want = dict(last=1, fused96=3, fused192=3, s1=6, ring192_t7=6, ring192_t2=3, h3=2, f32=0, stream96=0, stream192=0,
+                ring96_t7=0, ring96_t2=0, ring96_t1=0, ring192_t1=0)
+    if frames_ge_1024:
+        want.update(ring192_t7=7, ring192_t2=4, h3=0)
+    return want
+
+
+@pytest.mark.parametrize("name", ["dac_mini_f300", "dac_mini_f2571"])
+def test_dac_production_kernels_against_the_oracle_at_production_sizes(hip, name):
+    """The kernels that decode the benchmark's clips - LDS-DMA ring (7-tap and transposed instances), windowless wide 1x1
+    (conv_kernel_s1), fused residual units (96 / 192 wide), last-layer reduction - against the structural oracle itself
+    (transformers DacModel with the same weights, oracle/gen_golden.py --only-dac-long), at sizes where the DEFAULT dispatch
+    selects them: 2 x 300 frames (whole waveform) and 1 x 2571 frames = the benchmark clip (every 64th sample, float64 sums
+    and sums of squares over every 4096-sample block, whole windows at the head, across the middle tile seams, around frame
+    1000 and at the tail).  No PTTS_DAC_* switch is set; the launch tallies prove which kernels produced the waveform."""
+    from parler_tts_amd import _hip
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    assert not [k for k in os.environ if k.startswith("PTTS_DAC_")], "this test is about the default dispatch"
+    f, _ = load_case(name)
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=int(f["seed"]), parts=("audio_encoder",))
+    dac = DACModel(cfg, sd, device="cuda:0")
+    codes = torch.from_numpy(f["codes"])
+    dac.decode(codes[None, :, :, :8], [None])            # weights packed, workspaces allocated
+    _hip.dac_kernel_counts(reset=True)
+    wav = dac.decode(codes[None], [None]).audio_values.cpu().double().reshape(codes.shape[0], -1)
+    counts = _hip.dac_kernel_counts(reset=True)
+    assert counts == _production_kernel_counts(codes.shape[-1] >= 1024), counts
+    if "wav" in f:
+        ref = torch.from_numpy(f["wav"]).double().reshape(codes.shape[0], -1)
+        d = wav - ref
+        assert wav.shape == ref.shape and float(ref.abs().max()) > 0.05
+        assert float(d.pow(2).mean().sqrt()) < 1e-5 and float(d.abs().max()) < 1e-4, (float(d.pow(2).mean().sqrt()), float(d.abs().max()))
+        return
+    n, stride, block = int(f["n_samples"]), int(f["stride"]), int(f["block"])
+    assert wav.shape[1] == n
+    d = wav[:, ::stride] - torch.from_numpy(f["wav_stride"]).double()
+    assert float(d.pow(2).mean().sqrt()) < 1e-5 and float(d.abs().max()) < 1e-4, (float(d.pow(2).mean().sqrt()), float(d.abs().max()))
+    nb = (n + block - 1) // block
+    pad = torch.zeros(wav.shape[0], nb * block - n, dtype=wav.dtype)
+    sums = torch.cat([wav, pad], 1).reshape(wav.shape[0], nb, block).sum(-1)
+    sq = torch.cat([wav * wav, pad], 1).reshape(wav.shape[0], nb, block).sum(-1)
+    ref_s, ref_q = torch.from_numpy(f["block_sums"]), torch.from_numpy(f["block_sqsums"])
+    # a mean error of 1e-5 per sample over a block, and the matching bound on the energy (2 |x| |dx| summed)
+    assert float((sums - ref_s).abs().max()) < block * 1e-5, float((sums - ref_s).abs().max())
+    assert float(((sq - ref_q).abs() / (2e-5 * block * ref_q.div(block).sqrt() + 1e-9)).max()) < 1.0
+    for i in range(int(f["n_windows"])):
+        a, b = (int(x) for x in f[f"win{i}_range"])
+        dw = wav[:, a:b] - torch.from_numpy(f[f"win{i}"]).double()
+        assert float(dw.pow(2).mean().sqrt()) < 1e-5 and float(dw.abs().max()) < 1e-4, (i, float(dw.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------
 # codec, encode direction (audio prompts): DAC encoder conv stack + residual vector quantiser
 # ------------------------------------------------------------------------------------------------
@@ -966,6 +1024,27 @@ def test_dac_encode_kernels(hip, name):
     # encode -> decode -> shapes of the round trip (D:98-134 takes what D:25-96 returns)
     wav = dac.decode(out.audio_codes, out.audio_scales).audio_values
     assert wav.shape == (B, 1, F * cfg.audio_encoder.hop_length)
+
+
+def test_dac_encode_against_the_oracle_at_one_second_of_audio(hip):
+    """ptts_dac_encode at 1.2 s of audio (2 x 52813 samples, not a hop multiple; several 512-row workgroups per layer and
+    tile seams in every block) vs transformers' DacModel.encode (fixture dac_enc_mini_long): codes bit-exact, latent 2e-5."""
+    from parler_tts_amd import _hip
+
+    f, _ = load_case("dac_enc_mini_long")
+    cfg, sd, dac = _codec_with_encoder("dac_mini", int(f["seed"]))
+    B, T = int(f["B"]), int(f["T"])
+    gg = torch.Generator().manual_seed(int(f["seed_in"]))
+    audio = (torch.rand(B, 1, T, generator=gg) * 2 - 1) * 0.5
+    _hip.dac_kernel_counts(reset=True)
+    codes = dac.encode(audio).audio_codes.cpu()
+    counts = _hip.dac_kernel_counts(reset=True)
+    assert counts["f32"] == 0 and counts["h3"] > 0, counts        # every MFMA layer on the fp16 x 3 fast path
+    F = T // cfg.audio_encoder.hop_length
+    assert codes.shape == f["codes"].shape == (1, B, cfg.audio_encoder.num_codebooks, F)
+    z = _codec_latent(dac, B, F, cfg.audio_encoder.latent_dim).numpy()[:, :, :: int(f["latent_stride"])]
+    assert np.abs(z - f["latent"]).max() < 2e-5 * max(1.0, float(np.abs(f["latent"]).max())), np.abs(z - f["latent"]).max()
+    assert np.array_equal(codes.numpy(), f["codes"])
 
 
 def test_dac_encode_batch_and_length_invariants(hip):
