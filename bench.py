@@ -89,7 +89,7 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=25.0, full_b1=False):
             cache.cross_k.append(torch.randn(Bx, H, T, D // H) * 0.1)
             cache.cross_v.append(torch.randn(Bx, H, T, D // H) * 0.1)
         cache.length = S0
-        ids = torch.randint(0, 1024, (Bx * K, 1))
+        ids = torch.randint(0, min(1024, dec.vocab_size), (Bx * K, 1))
         cpu_ref.decoder_forward(cfg, sd, ids, enc_h, amask, None, None, cache)   # warm-up
         ts = []
         for _ in range(n):
@@ -110,23 +110,45 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=25.0, full_b1=False):
     steps = L - 1
 
     def leg(Bx, mode, budget):
-        t_lo, s_lo = timed_steps(Bx, P + 1, 6, mode)
-        n_hi = max(2, min(6, int((budget - 6 * t_lo) / max(t_lo * 6, 1e-3))))
-        t_hi, s_hi = timed_steps(Bx, P + L // 2, n_hi, mode)
-        slope = (t_hi - t_lo) / max(s_hi - s_lo, 1)
-        total = sum(t_lo + slope * ((P + 1 + i) - s_lo) for i in range(steps))
-        return Bx * K * steps / total, (f"6 steps at S~{s_lo} ({t_lo * 1e3:.0f} ms/step) and {n_hi} at S~{s_hi} "
-                                        f"({t_hi * 1e3:.0f} ms/step)")
+        """per-step time sampled at four cache lengths over the run (start, 1/4, 1/2, 3/4), least-squares quadratic in S
+        (cat-grown: the re-copy and the attention are both linear in S, cache misses bend it upwards), integrated over every
+        step of the run; returns (tokens/s, description, max relative residual of the fit)"""
+        import numpy as np
 
-    v_cat, d_cat = leg(B, "cat", budget_s * 0.55)
-    v_static, d_static = leg(B, "static", budget_s * 0.35)
-    v_b1, d_b1 = leg(1, "cat", budget_s * 0.1)
+        t0, s0 = timed_steps(Bx, P + 1, 6, mode)
+        pts = [(s0, t0)]
+        # what the later points will cost, from a first look at the middle of the run
+        t_mid, s_mid = timed_steps(Bx, P + L // 2, 2, mode)
+        pts.append((s_mid, t_mid))
+        spent = 7 * t0 + 3 * t_mid
+        for frac in (0.25, 0.75):
+            est = t0 + (t_mid - t0) * (frac / 0.5)
+            if spent + 3 * est > budget and len(pts) >= 3:
+                break
+            t, sx = timed_steps(Bx, P + int(L * frac), 2, mode)
+            pts.append((sx, t))
+            spent += 3 * t
+        pts.sort()
+        S = np.array([p[0] for p in pts], dtype=np.float64)
+        Tm = np.array([p[1] for p in pts], dtype=np.float64)
+        deg = 2 if len(pts) >= 4 else 1
+        coef = np.polyfit(S, Tm, deg)
+        resid = float(np.max(np.abs(np.polyval(coef, S) - Tm) / Tm))
+        s_all = P + 1 + np.arange(steps, dtype=np.float64)
+        total = float(np.maximum(np.polyval(coef, s_all), Tm.min() * 0.5).sum())
+        desc = ", ".join(f"S~{int(a)}: {b * 1e3:.0f} ms/step" for a, b in pts) + f"; degree-{deg} fit, max residual {resid * 100:.1f} %"
+        return Bx * K * steps / total, desc, resid
+
+    v_cat, d_cat, r_cat = leg(B, "cat", budget_s * 0.55)
+    v_static, d_static, r_static = leg(B, "static", budget_s * 0.35)
+    v_b1, d_b1, r_b1 = leg(1, "cat", budget_s * 0.1)
     out = {
         "value": round(v_cat, 2), "unit": "codec tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
         "static_kv_value": round(v_static, 2), "batch1_value": round(v_b1, 2),
-        "sample": (f"decode loop only (no T5/DAC), fp32, {cores} torch threads, each leg integrated over {steps} steps with a "
-                   f"linear-in-S model: value = B={B} reference-shaped cat-grown KV [{d_cat}]; static_kv_value = B={B} "
-                   f"preallocated KV [{d_static}]; batch1_value = B=1 cat-grown [{d_b1}]"),
+        "fit_max_rel_residual": {"cat": round(r_cat, 4), "static": round(r_static, 4), "batch1": round(r_b1, 4)},
+        "sample": (f"decode loop only (no T5/DAC), fp32, {cores} torch threads, each leg = per-step times sampled along the run, "
+                   f"fitted in S and integrated over {steps} steps: value = B={B} reference-shaped cat-grown KV [{d_cat}]; "
+                   f"static_kv_value = B={B} preallocated KV [{d_static}]; batch1_value = B=1 cat-grown [{d_b1}]"),
     }
     if full_b1:      # one FULL batch-1 run of the port (minutes; BASELINE.md section 4.3), not part of the default bench
         enc = torch.randn(1, T, cfg.text_encoder.d_model)
@@ -136,6 +158,61 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=25.0, full_b1=False):
         dt = time.perf_counter() - t0
         out["batch1_full_run"] = {"seconds": round(dt, 1), "codec_tokens_per_s": round(K * (r["raw_ids"].shape[1] - 1) / dt, 2)}
     return out
+
+
+def make_one_pass(model, cfg, desc, amask, prompt, kw, dist, rank, world, dev, coll_dev, B, L, timings=None):
+    """One bench "step".  N = 1: a plain generate().  N > 1: the whole job's batch (B per GPU) lives on rank 0 and goes through
+    parler_tts_amd.distributed.generate_data_parallel - scatter of the id slices, local generate(), gather of the codec ids
+    with per-row lengths - i.e. the call a multi-GPU user makes, inside the timed region.  `timings` collects this rank's
+    scatter / generate / gather wall times of the last pass."""
+    K = cfg.decoder.num_codebooks
+    if dist is None:
+        return lambda: model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, **kw)
+    from parler_tts_amd.distributed import generate_data_parallel
+
+    def local(**inp):      # full local generate() (waveforms stay on the rank), codec ids go to the gather
+        model.generate(**{k: v.to(dev) for k, v in inp.items()}, **kw)
+        return model.last_codes[0].to(coll_dev)
+
+    def one_pass():
+        src = dict(input_ids=desc.to(coll_dev), attention_mask=amask.to(coll_dev), prompt_input_ids=prompt.to(coll_dev)) \
+            if rank == 0 else dict(input_ids=None, attention_mask=None, prompt_input_ids=None)
+        codes, frames = generate_data_parallel(local, **src, src=0, device=coll_dev, gather="codes",
+                                               pad_token_id=cfg.decoder.pad_token_id, timings=timings)
+        assert codes.shape[0] == B * world and int(frames.min()) == L - K
+        return codes
+
+    return one_pass
+
+
+def dp_report(dist, world, coll_dev, phase, timings, steps, value, root=ROOT):
+    """What makes an N > 1 line checkable: the rank count the process group really has, the backend, min / max over ranks of
+    the per-pass phases (all-gathered), and the weak-scaling efficiency against the newest single-GPU record on disk."""
+    mine = torch.tensor([phase["t5_prefill_ms"] / steps, phase["decode_ms"] / steps, phase["post_ms"] / steps,
+                         timings.get("scatter_ms", 0.0), timings.get("generate_ms", 0.0), timings.get("gather_ms", 0.0)],
+                        dtype=torch.float64, device=coll_dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    m = torch.stack(parts).cpu()
+    names = ["t5_prefill_ms", "decode_ms", "post_ms", "scatter_ms_last_pass", "generate_ms_last_pass", "gather_ms_last_pass"]
+    rep = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+           "per_rank_min_max": {n: [round(float(m[:, i].min()), 2), round(float(m[:, i].max()), 2)] for i, n in enumerate(names)},
+           "slowest_rank_by_decode": int(m[:, 1].argmax())}
+    n1, src = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(root, "BENCH_r*.json")), reverse=True) + [os.path.join(root, "profiles", "r03_bench_default.json")]:
+        try:
+            rec = json.load(open(path))
+            rec = rec.get("parsed", rec)
+            if rec.get("n_gpus") == 1 and rec.get("value"):
+                n1, src = float(rec["value"]), os.path.relpath(path, root)
+                break
+        except Exception:
+            continue
+    rep["n1_value"] = n1
+    rep["n1_source"] = src
+    rep["efficiency_vs_n1"] = round(value / (world * n1), 4) if n1 else None
+    return rep
 
 
 def main():
@@ -199,21 +276,8 @@ def main():
         kw["return_raw_ids"] = True
     coll_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
-    def one_pass():
-        if dist is None:
-            return model.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, **kw)
-        from parler_tts_amd.distributed import generate_data_parallel
-
-        def local(**inp):      # full local generate() (waveforms stay on the rank), codec ids go to the gather
-            model.generate(**{k: v.to(dev) for k, v in inp.items()}, **kw)
-            return model.last_codes[0].to(coll_dev)
-
-        src = dict(input_ids=desc.to(coll_dev), attention_mask=amask.to(coll_dev), prompt_input_ids=prompt.to(coll_dev)) \
-            if rank == 0 else dict(input_ids=None, attention_mask=None, prompt_input_ids=None)
-        codes, frames = generate_data_parallel(local, **src, src=0, device=coll_dev, gather="codes",
-                                               pad_token_id=cfg.decoder.pad_token_id)
-        assert codes.shape[0] == B * world and int(frames.min()) == L - K
-        return codes
+    timings = {}
+    one_pass = make_one_pass(model, cfg, desc, amask, prompt, kw, dist, rank, world, dev, coll_dev, B, L, timings)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -247,6 +311,7 @@ def main():
     F = L - K
     audio_s = B * F / cfg.audio_encoder.frame_rate * args.steps * world
     prof = model.engine().profile_read(reset=True)
+    dp = dp_report(dist, world, coll_dev, phase, timings, args.steps, tokens / dt) if dist is not None else None
     if rank == 0:
         achieved = (prof.algo_bytes / 1e9) / (prof.total_ms / 1e3) if prof.total_ms > 0 else 0.0
         # HBM traffic of the dominant kernel: NOT a counter reading of this run.  rocprofv3 --pmc passes (separate runs,
@@ -271,8 +336,8 @@ def main():
             "config": {"workload": f"parler_tts_mini_v0.1 {args.dtype}, batch {B}/GPU greedy, T={T} P={P} max_length={L} "
                                    f"({n_steps} decode steps), full generate() incl. T5 encoder, prefill and DAC decode"
                                    + (" [DAC skipped]" if args.no_dac else "")
-                                   + ("" if world == 1 else "; whole batch on rank 0 -> generate_data_parallel (broadcast ids, "
-                                      "slice, local generate, gather codec ids)"),
+                                   + ("" if world == 1 else "; whole batch on rank 0 -> generate_data_parallel (scatter id "
+                                      "slices, local generate, gather codec ids)"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "rtf_audio_s_per_wall_s": round(audio_s / dt, 2),
             "decode_loop_tokens_per_s": round(tokens / world / max(phase["decode_ms"] / 1e3, 1e-9), 1) if phase["decode_ms"] else None,
@@ -299,11 +364,18 @@ def main():
                 "sampled_step_ms_eager": round(prof.step_ms / max(prof.steps, 1), 3),
             },
         }
+        if dp is not None:
+            line["data_parallel"] = dp
+        line["profile_every"] = args.profile_every    # every n-th decode step of the timed region runs eagerly with events
         if world == 1 and not args.no_cpu_baseline:
             sd_dec = {k: v for k, v in sd.items() if not k.startswith(("text_encoder.", "audio_encoder."))}
             line["cpu_baseline"] = cpu_baseline(cfg, sd_dec, B, T, P, L, full_b1=args.cpu_full_b1)
-            line["speedup_vs_cpu_decode_loop"] = round(line["decode_loop_tokens_per_s"] / line["cpu_baseline"]["value"], 1) \
-                if line["decode_loop_tokens_per_s"] else None
+            if line["decode_loop_tokens_per_s"]:
+                # the static-KV leg first: it is the fair algorithmic baseline; the reference-shaped leg is dominated by the
+                # reference's own torch.cat re-copy of the cache (M:303-304)
+                line["speedup_vs_cpu_decode_loop"] = {
+                    "vs_static_kv_port": round(line["decode_loop_tokens_per_s"] / line["cpu_baseline"]["static_kv_value"], 1),
+                    "vs_reference_shaped_cat_kv_port": round(line["decode_loop_tokens_per_s"] / line["cpu_baseline"]["value"], 1)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -104,6 +104,7 @@ struct ptts_engine {
     size_t esz = 4;
     int Vp = 0;  // per-head vocab padded to 16
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;   // parallel to `allocs` (PTTS_DUMP_ALLOCS: address ranges, to attribute a faulting address)
     std::set<std::string> loaded;
     // decoder weights
     std::vector<DecLayer> layers;
@@ -220,6 +221,7 @@ int dev_alloc(ptts_engine* e, void** p, size_t bytes) {
     hipError_t r = hipMalloc(p, bytes);
     if (r != hipSuccess) return fail(PTTS_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(r));
     e->allocs.push_back(*p);
+    e->alloc_bytes.push_back(bytes);
     return PTTS_OK;
 }
 
@@ -343,6 +345,24 @@ Work decode_work(ptts_engine* e) {
 // batched prefill (npos > 0): M = B_eff * npos rows, row b * npos + i = cache position pos0 + i of utterance b; the QKV
 // epilogue appends every row's k / v at its own position, self-attention is causal over the cache (attn_causal_kernel),
 // cross-attention rows read their utterance's description keys.  Same GEMM kernels (m-tiles in gridDim.y).
+// PTTS_DUMP_ALLOCS=<file>: the device address ranges this engine owns (dev_alloc) plus the named pools, written once per
+// prefill - lets a faulting address reported by a tool (e.g. a profiler abort) be attributed to an allocation or ruled out
+void dump_allocs(const ptts_engine* e) {
+    const char* path = getenv("PTTS_DUMP_ALLOCS");
+    if (!path) return;
+    FILE* f = fopen(path, "w");
+    if (!f) return;
+    for (size_t i = 0; i < e->allocs.size(); ++i) {
+        const char* tag = e->allocs[i] == e->self_pool ? "self_pool" : (e->allocs[i] == e->cross_pool ? "cross_pool" : "");
+        fprintf(f, "%p %p %zu %s\n", e->allocs[i], (void*)((char*)e->allocs[i] + e->alloc_bytes[i]), e->alloc_bytes[i], tag);
+    }
+    const void* extra[] = {e->pf.x, e->pf.q, e->pf.attn_frag, e->pf.mlp_frag, e->pf.x_frag, e->pf.x_frag2, e->dac_buf0, e->dac_buf1};
+    const char* names[] = {"pf.x", "pf.q", "pf.attn_frag", "pf.mlp_frag", "pf.x_frag", "pf.x_frag2", "dac_buf0", "dac_buf1"};
+    for (int i = 0; i < 8; ++i)
+        if (extra[i]) fprintf(f, "%p ? ? %s\n", extra[i], names[i]);
+    fclose(f);
+}
+
 int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int M, int npos = 0, int pos0 = 0) {
     const ptts_config& c = e->cfg;
     const int D = c.hidden, F = c.ffn;
@@ -1247,6 +1267,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     e->prefilled = true;
     e->half_pending = false;
     e->prompt_embeds = nullptr;       // one-shot
+    dump_allocs(e);
     return leave_stream(e, stream, s);
 }
 

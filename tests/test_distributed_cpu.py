@@ -111,3 +111,109 @@ def test_shard_bounds_cover_the_batch():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---- bench.py's N > 1 path: the one_pass() closure and the checkable fields of its JSON line, with a fake model ----
+class _FakeCfg:
+    class decoder:
+        num_codebooks = 3
+        pad_token_id = PAD
+
+
+class _FakeModel:
+    """stands for ParlerTTSForConditionalGeneration: generate() leaves codec ids [1, b, K, F] in .last_codes"""
+
+    def __init__(self, L):
+        self.L, self.seen = L, []
+
+    def generate(self, input_ids, attention_mask=None, prompt_input_ids=None, **kw):
+        self.seen.append(tuple(input_ids.shape))
+        K, F = _FakeCfg.decoder.num_codebooks, self.L - _FakeCfg.decoder.num_codebooks
+        base = input_ids.sum(dim=1).view(-1, 1, 1) + prompt_input_ids.sum(dim=1).view(-1, 1, 1)
+        self.last_codes = (((base + torch.arange(K).view(1, K, 1) + 5 * torch.arange(F).view(1, 1, F)) % 1024)[None])[0][None]
+        return None
+
+
+def _bench_worker(rank, world, port, B, L, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+
+    g = torch.Generator().manual_seed(9)
+    desc = torch.randint(2, 100, (B * world, 6), generator=g)
+    prompt = torch.randint(2, 100, (B * world, 4), generator=g)
+    amask = torch.ones(B * world, 6, dtype=torch.long)
+    model, timings = _FakeModel(L), {}
+    cpu = torch.device("cpu")
+    one_pass = bench.make_one_pass(model, _FakeCfg, desc, amask, prompt, dict(do_sample=False, max_length=L), dist, rank, world,
+                                   cpu, cpu, B, L, timings)
+    codes = one_pass()
+    phase = {"t5_prefill_ms": 1.0 + rank, "decode_ms": 100.0 * (1 + rank), "post_ms": 10.0}
+    rep = bench.dp_report(dist, world, cpu, phase, timings, 1, 1000.0, root="/nonexistent")
+    out_q.put((rank, codes.clone(), list(model.seen), rep, dict(timings)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_one_pass_and_dp_report_world2():
+    world, B, L = 2, 3, 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, B, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(9)
+    desc = torch.randint(2, 100, (B * world, 6), generator=g)
+    prompt = torch.randint(2, 100, (B * world, 4), generator=g)
+    ref_model = _FakeModel(L)
+    ref_model.generate(desc, None, prompt)
+    for r in range(world):
+        codes, seen, rep, timings = got[r]
+        assert torch.equal(codes, ref_model.last_codes[0])          # whole job's codes on every rank
+        assert seen == [(B, 6)]                                      # a rank generated ITS slice only (scatter, not broadcast)
+        assert rep["ranks"] == world and rep["backend"] == "gloo"
+        assert rep["per_rank_min_max"]["decode_ms"] == [100.0, 200.0] and rep["slowest_rank_by_decode"] == 1
+        assert rep["efficiency_vs_n1"] is None and rep["n1_source"] is None
+        assert set(timings) == {"scatter_ms", "generate_ms", "gather_ms"}
+
+
+def _bad_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids, mask, prompt = _inputs(4)
+    args = dict(input_ids=ids, attention_mask=mask, prompt_input_ids=prompt) if rank == 0 else \
+        dict(input_ids=None, attention_mask=None, prompt_input_ids=None)
+
+    def broken(**kw):      # rank 1 returns one row too many
+        c = fake_generate(**kw)
+        return torch.cat([c, c[:1]]) if rank == 1 else c
+
+    try:
+        generate_data_parallel(broken, **args, src=0, device="cpu", gather="codes", pad_token_id=PAD)
+        out_q.put((rank, "no error"))
+    except ValueError as e:
+        out_q.put((rank, "ValueError"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_wrong_row_count_raises_on_every_rank_instead_of_hanging():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: "ValueError", 1: "ValueError"}

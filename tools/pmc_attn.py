@@ -4,9 +4,13 @@ this image).  Builds a 2-layer engine at mini_v0.1 widths through the C ABI with
 runs a bf16 batch-32 greedy decode to S = max_length, so that the self-attention kernel's HBM traffic
 (FETCH_SIZE) can be compared with its algorithmic bytes 2*B*S*D*2 per launch.
 
-    PTTS_NO_GRAPH=1 rocprofv3 --pmc TCC_EA0_RDREQ_sum --output-format csv -d out -- python3 tools/pmc_attn.py [L] [layers] [P]
-(PTTS_NO_GRAPH=1: rocprofv3 --pmc aborts inside librocprofiler-sdk on hipGraphLaunch replays, profiles/README.md;
- `2580 24 16` is the decode loop of the bench workload: 24 layers, batch 32, T = 40, P = 16, 2579 steps)
+    rocprofv3 --pmc TCC_EA0_RDREQ_sum --output-format csv -d out -- python3 tools/pmc_attn.py [L] [layers] [P]
+`900 1` (one layer, S <= 899) is the configuration recorded as completing under --pmc; larger ones (`1400 2`, `2580 24 16` = the
+bench workload's decode loop) are recorded as aborting inside librocprofiler-sdk in most passes, with or without
+PTTS_NO_GRAPH=1 (profiles/r02_rocprofv3_pmc_abort_symbolized.txt, profiles/r03_pmc_abort_root_cause.txt).  A long context
+with FEW launches: a long prompt, e.g. `580 1 2000` (S = 2001 .. 2579 over 579 steps; the prompt positions go through the
+batched prefill).   PTTS_PMC_BATCH=n: utterances (default 32).   PTTS_DUMP_MAPS=<file>: /proc/self/maps written AFTER the first
+decode step (when the HSA queues of the launch path exist), PTTS_DUMP_ALLOCS=<file>: the engine's own device ranges.
 """
 import ctypes as C
 import os
@@ -37,7 +41,7 @@ def main():
     lib = _hip.load_library()
     NL = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     P = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # prompt positions (bench: 16)
-    B, T, D, H, F, V, K, ENC = 32, 40, 1024, 16, 4096, 1088, 9, 768
+    B, T, D, H, F, V, K, ENC = int(os.environ.get("PTTS_PMC_BATCH", "32")), 40, 1024, 16, 4096, 1088, 9, 768
     c = _hip.PttsConfig()
     c.abi_version, c.dtype = _hip.ABI_VERSION, _hip.DTYPE_BF16
     c.hidden, c.layers, c.heads, c.ffn, c.vocab, c.codebooks, c.max_positions = D, NL, H, F, V, K, 4096
@@ -46,9 +50,6 @@ def main():
     c.max_batch, c.max_desc_len, c.max_prompt_len, c.max_length = B, T, P, L
     h = C.c_void_p()
     _hip.check(lib.ptts_create(C.byref(c), C.byref(h)))
-    if os.environ.get("PTTS_DUMP_MAPS"):      # address map of this process, to symbolise a profiler abort afterwards
-        with open("/proc/self/maps") as src, open(os.environ["PTTS_DUMP_MAPS"], "w") as dst:
-            dst.write(src.read())
     rng = np.random.default_rng(0)
 
     def load(name, shape, std=0.02, ones=False, zero_from=None):
@@ -90,7 +91,12 @@ def main():
     pids = dev(rng.integers(0, 64, (B, max(P, 1))).astype(np.int64)) if P else None
     _hip.check(lib.ptts_prefill(h, B, B, T, P, L, enc, amask, pids, None, d_pat, d_raw, 1, None))
     sp = _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
-    _hip.check(lib.ptts_decode_steps(h, L - 1, C.byref(sp), 0, None))
+    _hip.check(lib.ptts_decode_steps(h, 1, C.byref(sp), 0, None))
+    hip.hipDeviceSynchronize()
+    if os.environ.get("PTTS_DUMP_MAPS"):      # address map of this process, to symbolise a profiler abort afterwards
+        with open("/proc/self/maps") as src, open(os.environ["PTTS_DUMP_MAPS"], "w") as dst:
+            dst.write(src.read())
+    _hip.check(lib.ptts_decode_steps(h, L - 2, C.byref(sp), 0, None))
     hip.hipDeviceSynchronize()
     st = _hip.PttsState()
     _hip.check(lib.ptts_get_state(h, C.byref(st), None))
