@@ -68,6 +68,14 @@ typedef struct ptts_config {
     int32_t dac_up[8];          /* upsampling strides, e.g. 8,8,4,2 */
     /* codec encoder (audio prompts): descript `encoder_dim` (64); its strides are dac_up reversed; 0 = engine without it */
     int32_t dac_enc_hidden;
+    /* decoder-op variants for random-init scaled-decoder studies (EXTENSIONS: the reference's decoder has LayerNorm with bias,
+     * additive sinusoidal positions and a 2-matrix GELU MLP, modeling_parler_tts.py:402-413, :181-223, :488-490, and no switch):
+     * bit 0 RMSNorm (x * rsqrt(mean(x^2) + 1e-5) * weight; the *.layer_norm.bias tensors are accepted and ignored),
+     * bit 1 rotary positions on the self-attention (pairs (i, i + 32) per head; tables decoder.rope.cos / decoder.rope.sin
+     *       [max_positions][32] fp32 arrive through ptts_load_tensor; no additive position table),
+     * bit 2 SwiGLU MLP (fc2(silu(fc1(x)) * fc1_up(x)); extra tensor decoder.model.decoder.layers.{l}.fc1_up.weight [ffn][hidden]).
+     * 0 = the reference's ops. */
+    int32_t dec_variant;
 } ptts_config;
 
 typedef struct ptts_engine ptts_engine;

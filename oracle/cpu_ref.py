@@ -168,8 +168,22 @@ def decoder_forward(
     return_hidden: bool = False,
     decoder_attention_mask: Optional[torch.Tensor] = None,   # [B, past_generated + q_in] or None
 ):
-    """ParlerTTSDecoder.forward + 9 LM heads: M:794-978, M:1096-1185.  Returns logits [B*K, q, V]."""
+    """ParlerTTSDecoder.forward + 9 LM heads: M:794-978, M:1096-1185.  Returns logits [B*K, q, V].
+
+    The `norm_type` / `position_embedding` / `mlp_type` branches restate the decoder-op VARIANTS of configuration.py
+    (RMSNorm, rotary positions on the self-attention, SwiGLU).  They follow no line of the reference - its decoder has none of
+    them - so everything tested through them is "unpinned by the reference": this plain fp32
+    PyTorch statement is the only checker that can exist for them."""
     dec = cfg.decoder
+    rms = getattr(dec, "norm_type", "layer_norm") == "rms_norm"
+    rope = getattr(dec, "position_embedding", "sinusoidal") == "rope"
+    swiglu = getattr(dec, "mlp_type", "gelu") == "swiglu"
+
+    def norm(t, wkey, bkey):
+        if rms:
+            return t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5) * sd[wkey]
+        return F.layer_norm(t, (t.shape[-1],), sd[wkey], sd[bkey])
+
     D, H, K, L = dec.hidden_size, dec.num_attention_heads, dec.num_codebooks, dec.num_hidden_layers
     hd = D // H
     pre = "decoder.model.decoder."
@@ -199,19 +213,32 @@ def decoder_forward(
         inv = 1.0 - encoder_attention_mask[:, None, None, :].to(dtype).expand(B, 1, tq, -1)
         cross_mask = inv.masked_fill(inv.bool(), _finfo_min(dtype))
 
-    pos = sd[f"{pre}embed_positions.weights"].index_select(0, torch.arange(tq) + past)  # M:219-223
-    x = x + pos                                                   # M:886
+    if not rope:
+        pos = sd[f"{pre}embed_positions.weights"].index_select(0, torch.arange(tq) + past)  # M:219-223
+        x = x + pos                                                   # M:886
     scaling = hd ** -0.5
+    if rope:      # variant: angles of the positions past .. past + tq - 1 (prompt positions count, as M:882-883 counts them)
+        from parler_tts_amd.weights import rope_tables      # the table recipe is data shared with the engine's loader, not engine code
+
+        cos_t, sin_t = rope_tables(dec, past + tq)
+        cos, sin = cos_t[past:past + tq][None, None], sin_t[past:past + tq][None, None]
+
+        def rot(t):       # [B, H, tq, hd]: pairs (i, i + hd / 2)
+            a, b = t[..., : hd // 2], t[..., hd // 2:]
+            return torch.cat([a * cos - b * sin, b * cos + a * sin], dim=-1)
 
     first = cache.length == 0 and len(cache.self_k) == 0
     for l in range(L):
         p = f"{pre}layers.{l}."
         # --- self attention, M:445-460 ---
         res = x
-        h = F.layer_norm(x, (D,), sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
+        h = norm(x, p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias")
         q = F.linear(h, sd[p + "self_attn.q_proj.weight"]) * scaling      # M:282
         k = _shape(F.linear(h, sd[p + "self_attn.k_proj.weight"]), B, H, hd)
         v = _shape(F.linear(h, sd[p + "self_attn.v_proj.weight"]), B, H, hd)
+        if rope:
+            q = rot(_shape(q, B, H, hd)).transpose(1, 2).reshape(B, tq, D)
+            k = rot(k)
         if cache.mode == "cat":
             if past > 0:
                 k = torch.cat([cache.self_k[l], k], dim=2)               # M:303-304
@@ -233,7 +260,7 @@ def decoder_forward(
         # --- cross attention, M:462-483 (the whole block is skipped without encoder states, M:465) ---
         if encoder_hidden_states is not None:
             res = x
-            h = F.layer_norm(x, (D,), sd[p + "encoder_attn_layer_norm.weight"], sd[p + "encoder_attn_layer_norm.bias"])
+            h = norm(x, p + "encoder_attn_layer_norm.weight", p + "encoder_attn_layer_norm.bias")
             q = F.linear(h, sd[p + "encoder_attn.q_proj.weight"]) * scaling
             if first:                                                        # M:295-298
                 cache.cross_k.append(_shape(F.linear(encoder_hidden_states, sd[p + "encoder_attn.k_proj.weight"]), B, H, hd))
@@ -242,11 +269,14 @@ def decoder_forward(
             x = res + F.linear(a, sd[p + "encoder_attn.out_proj.weight"])
         # --- MLP, M:485-492 ---
         res = x
-        h = F.layer_norm(x, (D,), sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
-        h = F.gelu(F.linear(h, sd[p + "fc1.weight"]))
+        h = norm(x, p + "final_layer_norm.weight", p + "final_layer_norm.bias")
+        if swiglu:
+            h = F.silu(F.linear(h, sd[p + "fc1.weight"])) * F.linear(h, sd[p + "fc1_up.weight"])
+        else:
+            h = F.gelu(F.linear(h, sd[p + "fc1.weight"]))
         x = res + F.linear(h, sd[p + "fc2.weight"])
     cache.length = past + tq
-    x = F.layer_norm(x, (D,), sd[f"{pre}layer_norm.weight"], sd[f"{pre}layer_norm.bias"])  # M:959
+    x = norm(x, f"{pre}layer_norm.weight", f"{pre}layer_norm.bias")  # M:959
     logits = torch.stack([F.linear(x, sd[f"decoder.lm_heads.{k}.weight"]) for k in range(K)], dim=1)  # M:1143
     logits = logits.reshape(-1, *logits.shape[2:])                      # M:1172
     if return_hidden:

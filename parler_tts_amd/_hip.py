@@ -40,6 +40,7 @@ class PttsConfig(C.Structure):
         ("dac_codebook_size", C.c_int32), ("dac_codebook_dim", C.c_int32), ("dac_latent", C.c_int32),
         ("dac_hidden", C.c_int32), ("dac_n_up", C.c_int32), ("dac_up", C.c_int32 * 8),
         ("dac_enc_hidden", C.c_int32),
+        ("dec_variant", C.c_int32),
     ]
 
 

@@ -104,12 +104,33 @@ class ParlerTTSDecoderConfig(_ConfigBase):
         # audio_channels is read at M:2042; mono unless a checkpoint says otherwise
         self.audio_channels = kwargs.pop("audio_channels", 1)
         self.cross_attention_hidden_size = kwargs.pop("cross_attention_hidden_size", None)
+        # Decoder-op variants for random-init "scaled decoder" studies (BASELINE configs[4]).  They are
+        # EXTENSIONS: the reference's decoder has LayerNorm with bias, additive sinusoidal positions and a 2-matrix GELU MLP
+        # (M:402-413, M:181-223, M:488-490) and no switch for anything else, so these have no oracle in the reference
+        # ("unpinned"); the defaults are the reference's ops.
+        #   norm_type          "layer_norm" | "rms_norm"  (x * rsqrt(mean(x^2) + 1e-5) * weight; the bias tensors are ignored)
+        #   position_embedding "sinusoidal" | "rope"      (no additive table; q, k of the SELF-attention rotated per head,
+        #                                                  pairs (i, i + head_dim / 2), angle pos * rope_theta^(-2 i / head_dim))
+        #   mlp_type           "gelu" | "swiglu"          (fc2(silu(fc1(x)) * fc1_up(x)); extra tensor layers.{l}.fc1_up.weight)
+        self.norm_type = kwargs.pop("norm_type", "layer_norm")
+        self.position_embedding = kwargs.pop("position_embedding", "sinusoidal")
+        self.rope_theta = float(kwargs.pop("rope_theta", 10000.0))
+        self.mlp_type = kwargs.pop("mlp_type", "gelu")
+        if self.norm_type not in ("layer_norm", "rms_norm") or self.position_embedding not in ("sinusoidal", "rope") or \
+                self.mlp_type not in ("gelu", "swiglu"):
+            raise ValueError("norm_type / position_embedding / mlp_type: unknown variant")
         self._extra = {k: v for k, v in kwargs.items() if not k.startswith("_")}
 
     def to_dict(self):
         d = super().to_dict()
         d.update(d.pop("_extra", {}))
         return d
+
+    @property
+    def variant_flags(self) -> int:
+        """bit 0 RMSNorm, bit 1 RoPE, bit 2 SwiGLU (ptts_config.dec_variant)"""
+        return (1 if self.norm_type == "rms_norm" else 0) | (2 if self.position_embedding == "rope" else 0) | \
+            (4 if self.mlp_type == "swiglu" else 0)
 
     @property
     def head_dim(self) -> int:
@@ -381,7 +402,7 @@ def scaled_config() -> ParlerTTSConfig:
 
 
 def tiny_config(num_codebooks: int = 4, hidden: int = 128, layers: int = 2, heads: int = 2, ffn: int = 256,
-                codebook_size: int = 64, enc_d: int = 64, max_positions: int = 256) -> ParlerTTSConfig:
+                codebook_size: int = 64, enc_d: int = 64, max_positions: int = 256, **decoder_variants) -> ParlerTTSConfig:
     """A toy architecture with the same structure, for second-scale CPU tests.
 
     hidden must be a multiple of 64 (head_dim is 64 as in every released Parler-TTS decoder).
@@ -397,6 +418,7 @@ def tiny_config(num_codebooks: int = 4, hidden: int = 128, layers: int = 2, head
         eos_token_id=codebook_size,
         bos_token_id=codebook_size + 1,
         num_codebooks=num_codebooks,
+        **decoder_variants,       # norm_type / position_embedding / rope_theta / mlp_type (extensions, ParlerTTSDecoderConfig)
     )
     t5 = T5EncoderConfig(vocab_size=512, d_model=enc_d, d_kv=32, d_ff=128, num_layers=2, num_heads=2)
     dac = DACConfig(num_codebooks=num_codebooks, codebook_size=codebook_size, latent_dim=64,

@@ -24,6 +24,7 @@ struct AttnArgs {
     const float* lnfix_c1 = nullptr;
     const float* lnfix_c2 = nullptr;
     float lnfix_eps = 1e-5f, lnfix_scale = 1.0f;
+    int lnfix_rms = 0;                   // RMSNorm variant of the folded projection: no centring (mean = 0, var = mean(x^2))
     // general kernel, self-attention only (len_from_state): `q` holds the RAW look-ahead product [q | k | v] (ldq = 3 D) of the
     // folded QKV projection; the kernel finishes the LayerNorm of its head's three 64-wide slices (c1 / c2 are [3 D]), scales
     // q, and appends the k / v rows to the cache at state->pos itself before it streams the cache
@@ -38,6 +39,9 @@ struct AttnArgs {
     // causal prefill kernel only: the launch covers positions pos0 .. pos0 + npos - 1 of every utterance; query row
     // b * npos + i sits at cache position pos0 + i and attends the keys 0 .. pos0 + i (M:870-872 causal mask)
     int npos = 0, pos0 = 0;
+#ifdef PTTS_STAMPS
+    StampRef stamps = {nullptr, -1};
+#endif
 };
 
 struct FullAttnArgs {

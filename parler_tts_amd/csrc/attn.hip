@@ -62,6 +62,14 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT;
     constexpr int STRIDE = NWAVES * UNR;                          // tiles between two bursts of one wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PTTS_STAMPS
+    // 0 realtime at entry, 1 cycles at entry, 2 first K burst issued, 3 scores done (pass 1), 4 softmax done, 5 P.V done,
+    // 6 output stored, 7 realtime at exit
+    unsigned long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const StampRef stref = a.stamps;
+    stv[0] = stamp_realtime();
+    stv[1] = stamp_cycles();
+#endif
     float* sc = reinterpret_cast<float*>(smem);                   // [S_cap] scores -> probabilities
     float* red = sc + a.s_cap;                                    // [NWAVES][64] partial outputs
     float* wred = red + NWAVES * 64;                              // [NWAVES] cross-wave scalars
@@ -71,6 +79,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     const int bu = b / a.rows_per_utt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int S = a.len_from_state ? (a.state->pos + 1) : a.len;
+    const int pos_append = S - 1;                                 // cache position of this step's own k / v (append-only cache)
     if (a.unfinished) {                                           // finished utterance: one key instead of the whole cache
         const int* u = a.unfinished + (bu % a.alive_b) * a.alive_k;
         int alive = 0;
@@ -94,8 +103,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         // Look-ahead QKV: `a.q` is the raw product x.Wqkv'^T this head's slices of which still need the LayerNorm of the
         // folded projection, rstd * (raw - mean * c1) + c2, from the per-block statistics the producing launch wrote.
         // Waves 0..2 take q, k, v (64 values each): q goes to LDS (scaled), k and v are appended to the cache at
-        // position S - 1; the barrier below (a workgroup-scope fence for global memory) orders the append before the
-        // streamed read of that row, which sits in the last tile of the stream.
+        // the step's own position (pos_append: NOT the shortened S - 1 of a finished utterance, whose streamed read stops
+        // at key 0 while its cache stays append-only); the barrier below (a workgroup-scope fence for global memory)
+        // orders the append before the streamed read of that row, which sits in the last tile of the stream.
         float* qs = reinterpret_cast<float*>(pages + a.pool.max_blocks);          // [64]
         if (w < 3) {
             const float* sp = a.lnfix_stat + ((size_t)(b >> 5) * a.lnfix_blocks * 32 + (b & 31)) * 2;
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
             const float y = rstd * (a.q[(size_t)b * a.ldq + n] - mean * a.lnfix_c1[n]) + a.lnfix_c2[n];
             if (w == 0) qs[lane] = y * a.lnfix_scale;
             else {
-                elem_t* dst = const_cast<elem_t*>(pool) + a.pool.elem_off(b, a.layer, w - 1, h, S - 1) + lane;
+                elem_t* dst = const_cast<elem_t*>(pool) + a.pool.elem_off(b, a.layer, w - 1, h, pos_append) + lane;
                 *dst = to_elem<P>(y);
             }
         }
@@ -160,6 +170,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     {
         int t0 = w;
         load_burst(bufA, t0, 0);
+#ifdef PTTS_STAMPS
+        stv[2] = stamp_cycles();
+#endif
         while (true) {
             bool more = t0 + STRIDE < ntiles;
             if (more) load_burst(bufB, t0 + STRIDE, 0);
@@ -176,6 +189,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     // first V burst goes out now: it does not depend on the probabilities and flies under the softmax
     load_burst(bufA, w, v_off);
     __syncthreads();
+#ifdef PTTS_STAMPS
+    stv[3] = stamp_cycles();
+#endif
 
     // ---------------- softmax over [0, S) ----------------
     float m = -INFINITY;
@@ -201,6 +217,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     for (int i = 0; i < NWAVES; ++i) sum += wred[i];
     for (int t = tid; t < S; t += NWAVES * 64) sc[t] = sc[t] / sum;
     __syncthreads();
+#ifdef PTTS_STAMPS
+    stv[4] = stamp_cycles();
+#endif
 
     // ---------------- pass 2: o = P.V ----------------
     float acc[EPL];
@@ -243,6 +262,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) red[w * 64 + c * EPL + j] = acc[j];
     }
+#ifdef PTTS_STAMPS
+    stv[5] = stamp_cycles();
+#endif
     __syncthreads();
     if (tid < PTTS_HEAD_DIM) {
         float o = 0.f;
@@ -251,6 +273,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(b >> 5) * 32 * a.D;
         of[frag_off<OP>(b & 31, h * PTTS_HEAD_DIM + tid)] = to_elem<OP>(o);
     }
+#ifdef PTTS_STAMPS
+    stv[6] = stamp_cycles();
+    stv[7] = stamp_realtime();
+    stamp_store(stref, stv);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -268,6 +295,13 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     typedef typename L::raw_t raw_t;
     constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT, NT = 64 / TPW;   // NT tiles cover one page
     const int lane = threadIdx.x & 63;
+#ifdef PTTS_STAMPS
+    // 0 realtime at entry, 1 cycles at entry, 6 cycles at the end, 7 realtime at exit (wave 0 of the workgroup)
+    unsigned long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const StampRef stref = a.stamps;
+    stv[0] = stamp_realtime();
+    stv[1] = stamp_cycles();
+#endif
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
     const int bu = b / a.rows_per_utt;          // query row b reads utterance bu's page and mask row
@@ -336,8 +370,8 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(vb[u]));
     if (lnfix) {
         const float K = (float)(a.lnfix_blocks * 16);
-        const float mean = wave_sum(st_s) / K;
-        const float var = fmaxf(wave_sum(st_q) / K - mean * mean, 0.f);
+        const float mean = a.lnfix_rms ? 0.f : wave_sum(st_s) / K;
+        const float var = a.lnfix_rms ? wave_sum(st_q) / K : fmaxf(wave_sum(st_q) / K - mean * mean, 0.f);
         const float rstd = 1.0f / sqrtf(var + a.lnfix_eps);
 #pragma unroll
         for (int j = 0; j < EPL; ++j) q[j] = a.lnfix_scale * (rstd * (q[j] - mean * fc1[j]) + fc2[j]);
@@ -391,6 +425,11 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) of[frag_off<OP>(b & 31, h * PTTS_HEAD_DIM + c * EPL + j)] = to_elem<OP>(acc[j]);
     }
+#ifdef PTTS_STAMPS
+    stv[6] = stamp_cycles();
+    stv[7] = stamp_realtime();
+    stamp_store(stref, stv);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

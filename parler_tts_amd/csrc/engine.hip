@@ -93,6 +93,7 @@ struct EventPair {
 struct Work {
     float *x = nullptr, *q = nullptr, *xstat = nullptr;
     void *attn_frag = nullptr, *mlp_frag = nullptr, *x_frag = nullptr, *x_frag2 = nullptr;
+    float* ffn_raw = nullptr;   // SwiGLU variant only: [rows][2 F] gate | up pre-activations
     int rows = 0;      // capacity (multiple of 32)
 };
 
@@ -126,6 +127,10 @@ struct ptts_engine {
     bool seq_prefill = false;  // PTTS_PREFILL_SEQ=1: the round-1 prefill, one cached position at a time (A/B, tests)
     int pf_chunk = 128;        // positions per batched-prefill chunk (PTTS_PREFILL_CHUNK)
     bool no_page_kernel = false;   // PTTS_ATTN_NO_PAGE_KERNEL=1: cross-attention on the general kernel (A/B, tests)
+    // decoder-op variants (ptts_config.dec_variant; extensions with no counterpart in the reference)
+    bool v_rms = false, v_rope = false, v_swiglu = false;
+    float *rope_cos = nullptr, *rope_sin = nullptr;   // [max_positions][32] fp32, handed in by the host (decoder.rope.cos / .sin)
+    float* ffn_raw = nullptr;                          // decode-step [rows][2 F]
     float *lnf_g = nullptr, *lnf_b = nullptr, *enc_proj_bias = nullptr;
     void *embed_tokens = nullptr, *pos_table = nullptr, *embed_prompts = nullptr;
     // T5
@@ -189,6 +194,10 @@ struct ptts_engine {
     bool no_graph = false;
     // debug: stop issuing kernels after dbg_stop launches of the current API call (-1 = off)
     int dbg_stop = -1, dbg_count = 0;
+#ifdef PTTS_STAMPS
+    unsigned long long* stamps = nullptr;   // diagnostic build: [PTTS_STAMP_SLOTS][PTTS_STAMP_WGS][8], slot = launch index in the step
+    int stamp_slot = -1;                    // next slot (-1: not inside a decode step)
+#endif
     // profile
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
@@ -289,9 +298,16 @@ int load_table(ptts_engine* e, void** dst, size_t total, size_t off, size_t n, c
 }
 
 #define DBG_GATE(e) do { if ((e)->dbg_stop >= 0 && (e)->dbg_count++ >= (e)->dbg_stop) return PTTS_OK; } while (0)
+#ifdef PTTS_STAMPS
+// diagnostic build: the launch about to be issued takes the next stamp slot of the decode step (gemm / attention kernels)
+#define STAMP_ARGS(e, args) do { if ((e)->stamp_slot >= 0) { (args).stamps.buf = (e)->stamps; (args).stamps.slot = (e)->stamp_slot++; } } while (0)
+#else
+#define STAMP_ARGS(e, args) do { } while (0)
+#endif
 
 // switch a LayerNorm-prologue projection to its folded form (fragment input = raw residual rows)
 void use_fold(const ptts_engine* e, GemmArgs* g, const Folded& f, int which = 0) {
+    if (e->v_rms) { g->rms = 1; if (g->pro == PRO_LAYERNORM) g->pro = PRO_RMSNORM; }    // variant: RMSNorm on either path
     if (!e->fold_ln) return;
     if (!(e->fold_mask & (1 << which))) return;      // PTTS_FOLD_MASK: bit 0 QKV, 1 cross-q, 2 fc1, 3 LM heads (A/B)
     g->W = f.w; g->pro = PRO_FRAG; g->xfrag = e->xf_cur; g->x = nullptr; g->fold = 1; g->c1 = f.c1; g->c2 = f.c2;
@@ -336,7 +352,7 @@ int refresh_folds(ptts_engine* e, hipStream_t s) {
 Work decode_work(ptts_engine* e) {
     Work w;
     w.x = e->x; w.q = e->q; w.xstat = e->xstat; w.attn_frag = e->attn_frag; w.mlp_frag = e->mlp_frag;
-    w.x_frag = e->x_frag; w.x_frag2 = e->x_frag2; w.rows = e->mtiles * 32;
+    w.x_frag = e->x_frag; w.x_frag2 = e->x_frag2; w.rows = e->mtiles * 32; w.ffn_raw = e->ffn_raw;
     return w;
 }
 
@@ -382,12 +398,21 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             use_fold(e, &g, w.qkv_f, 0);
             g.epi = EPI_QKV_SELF; g.out = wk.q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
             g.state = e->state; g.D = D; g.npos = npos; g.pos0 = pos0;
+            if (e->v_rope) { g.rope_k = 1; g.ldo = 2 * D; }      // q | unrotated k leave in fp32, v goes to the cache
             DBG_GATE(e);
+            STAMP_ARGS(e, g);
             PTTS_TRY(launch_gemm(e, g, s));
+            if (e->v_rope) {
+                RopeArgs ra;
+                ra.qk = wk.q; ra.ld = 2 * D; ra.D = D; ra.H = c.heads; ra.rows = M; ra.pool = make_pool(e, false); ra.layer = l;
+                ra.state = e->state; ra.npos = npos; ra.pos0 = pos0; ra.cos_t = e->rope_cos; ra.sin_t = e->rope_sin;
+                DBG_GATE(e);
+                HIP_TRY(rope_launch(ra, e->dt, s));
+            }
         }
         // self attention over the cached tokens
         AttnArgs a;
-        a.q = wk.q; a.ldq = D; a.pool = make_pool(e, false); a.layer = l; a.len_from_state = 1; a.state = e->state;
+        a.q = wk.q; a.ldq = e->v_rope ? 2 * D : D; a.pool = make_pool(e, false); a.layer = l; a.len_from_state = 1; a.state = e->state;
         a.bias = e->has_self_bias ? e->self_bias : nullptr; a.ld_bias = e->s_cap; a.s_cap = e->s_cap;
         a.ofrag = wk.attn_frag; a.D = D;
         if (npos == 0 && e->skip_finished) { a.unfinished = e->unfinished; a.alive_k = c.codebooks; a.alive_b = e->B; }
@@ -407,6 +432,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             HIP_TRY(attn_causal_launch(a, B_utt, c.heads, e->dt, e->dt, s));
         } else {
             // sampled launches carry their own start / stop events (hipExtLaunchKernel): the dispatch's timestamps
+            STAMP_ARGS(e, a);
             HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr));
         }
         // out_proj + residual (M:380, M:460)
@@ -426,6 +452,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             e->xf_cur = next;
         }
         DBG_GATE(e);
+        STAMP_ARGS(e, g);
         PTTS_TRY(launch_gemm(e, g, s));
         if (cross && !look) {
             // LN2 + cross-attention query (M:467-471)
@@ -435,6 +462,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             use_fold(e, &g, w.cq_f, 1);
             g.epi = EPI_Q_SCALE; g.out = wk.q; g.ldo = D; g.scale = scale;
             DBG_GATE(e);
+            STAMP_ARGS(e, g);
             PTTS_TRY(launch_gemm(e, g, s));
         }
         if (cross) {
@@ -447,14 +475,16 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             a.rows_per_utt = npos > 0 ? npos : 1;
             if (look) {
                 a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16; a.lnfix_c1 = w.cq_f.c1; a.lnfix_c2 = w.cq_f.c2;
-                a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
+                a.lnfix_eps = 1e-5f; a.lnfix_scale = scale; a.lnfix_rms = e->v_rms ? 1 : 0;
             }
             DBG_GATE(e);
+            STAMP_ARGS(e, a);
             HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
             g = GemmArgs();
             g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.attn_frag;
             g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
             DBG_GATE(e);
+            STAMP_ARGS(e, g);
             PTTS_TRY(launch_gemm(e, g, s));
         }
         // LN3 + fc1 + GELU(erf) -> fragments ; fc2 + residual (M:486-492)
@@ -463,8 +493,16 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
         g.pro = PRO_LAYERNORM; g.x = wk.x; g.ldx = D; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.eps = 1e-5f;
         use_fold(e, &g, w.fc1_f, 2);
         g.epi = EPI_ACT_FRAG; g.act = ACT_GELU; g.ofrag = wk.mlp_frag; g.ldo = F;
+        if (e->v_swiglu) {     // gated variant: [gate | up] pre-activations as one N = 2 F projection, then silu(gate) * up -> fragments
+            g.N = 2 * F; g.epi = EPI_ROWMAJOR; g.act = ACT_NONE; g.ofrag = nullptr; g.out = wk.ffn_raw; g.ldo = 2 * F;
+        }
         DBG_GATE(e);
+        STAMP_ARGS(e, g);
         PTTS_TRY(launch_gemm(e, g, s));
+        if (e->v_swiglu) {
+            DBG_GATE(e);
+            HIP_TRY(swiglu_frag_launch(wk.ffn_raw, wk.mlp_frag, M, F, e->dt, s));
+        }
         g = GemmArgs();
         g.W = w.fc2.ptr; g.N = D; g.K = F; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.mlp_frag;
         g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
@@ -479,6 +517,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             e->xf_cur = next;
         }
         DBG_GATE(e);
+        STAMP_ARGS(e, g);
         PTTS_TRY(launch_gemm(e, g, s));
     }
     return PTTS_OK;
@@ -499,6 +538,9 @@ int run_forward_half(ptts_engine* e, hipStream_t s, bool profile) {
     DBG_GATE(e);
     e->xf_cur = e->x_frag;
     HIP_TRY(embed_codebooks_launch(embed_args(e), e->B_eff, e->dt, s));
+#ifdef PTTS_STAMPS
+    e->stamp_slot = 0;      // slot = index of the gemm / attention launch inside the step (a replayed graph keeps its slots)
+#endif
     PTTS_TRY(run_layers(e, s, profile, decode_work(e), e->B_eff));
     DBG_GATE(e);
     // final LayerNorm (M:959) + the K LM heads (M:1143)
@@ -507,7 +549,11 @@ int run_forward_half(ptts_engine* e, hipStream_t s, bool profile) {
     g.pro = PRO_LAYERNORM; g.x = e->x; g.ldx = c.hidden; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.eps = 1e-5f;
     use_fold(e, &g, e->heads_f, 3);
     g.epi = EPI_ROWMAJOR; g.out = e->logits; g.ldo = c.codebooks * e->Vp;
+    STAMP_ARGS(e, g);
     PTTS_TRY(launch_gemm(e, g, s));
+#ifdef PTTS_STAMPS
+    e->stamp_slot = -1;
+#endif
     return PTTS_OK;
 }
 
@@ -811,13 +857,22 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
         return fail(PTTS_E_UNSUPPORTED, "hidden=%d needs the folded LayerNorm (PTTS_LN_FOLD=0 keeps rows of <= %d elements)",
                     cfg->hidden, cfg->dtype == PTTS_DTYPE_BF16 ? 2048 : 1024);
     }
+#ifdef PTTS_STAMPS
+    {   // diagnostic build: the stamp buffer exists before any stream capture
+        const size_t nb = (size_t)PTTS_STAMP_SLOTS * PTTS_STAMP_WGS * 8 * sizeof(unsigned long long);
+        if (hipMalloc((void**)&e->stamps, nb) == hipSuccess) (void)hipMemset(e->stamps, 0, nb);
+    }
+#endif
+    e->v_rms = (cfg->dec_variant & 1) != 0;
+    e->v_rope = (cfg->dec_variant & 2) != 0;
+    e->v_swiglu = (cfg->dec_variant & 4) != 0;
     e->no_page_kernel = getenv("PTTS_ATTN_NO_PAGE_KERNEL") != nullptr;
     e->lookahead = e->fold_ln;      // look-ahead cross-q rides on the folded LayerNorm (PTTS_LOOKAHEAD=0 switches it off)
     if (const char* v = getenv("PTTS_LOOKAHEAD")) e->lookahead = atoi(v) != 0;
     // look-ahead QKV: correct (parity tests) but SLOWER than the separate launch on this part (decode pass +6.7 %: the
     // product weights add 25 MB per layer to the fc2 launch), so it is an experiment switch only (PTTS_LOOKAHEAD2=1)
     e->lookahead2 = false;
-    if (const char* v = getenv("PTTS_LOOKAHEAD2")) e->lookahead2 = atoi(v) != 0 && e->fold_ln;
+    if (const char* v = getenv("PTTS_LOOKAHEAD2")) e->lookahead2 = atoi(v) != 0 && e->fold_ln && cfg->dec_variant == 0;
     if (const char* v = getenv("PTTS_LOOKAHEAD2_WIDE")) e->look2_wide = atoi(v) != 0;
     if (const char* v = getenv("PTTS_FOLD_MASK")) e->fold_mask = atoi(v);
     e->dac_f32_only = getenv("PTTS_DAC_F32") != nullptr;
@@ -899,7 +954,8 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->cross_table, sizeof(int) * Bm * e->cross_blocks);
     e->s_cap = e->self_blocks * PTTS_PAGE_TOKENS;
     A(e->x, sizeof(float) * rows * D);
-    A(e->q, sizeof(float) * rows * D);
+    A(e->q, sizeof(float) * rows * D * (e->v_rope ? 2 : 1));
+    if (e->v_swiglu) A(e->ffn_raw, sizeof(float) * rows * 2 * F);
     A(e->attn_frag, e->esz * rows * D);
     A(e->x_frag, e->esz * rows * D);
     A(e->x_frag2, e->esz * rows * D);
@@ -973,6 +1029,13 @@ int ptts_load_tensor(ptts_engine* e, const char* cname, const float* data, const
     } else if (name == "decoder.model.decoder.embed_positions.weights") {
         if (ndim != 2 || shape[0] < c.max_positions || shape[1] != D) return fail(PTTS_E_INVALID, "%s: bad shape", cname);
         rc = load_table(e, &e->pos_table, (size_t)c.max_positions * D, 0, (size_t)c.max_positions * D, data, s);
+        // rotary variant: no additive position table - the embed kernels keep adding this row, which is all zeros then
+        if (rc == PTTS_OK && e->v_rope) HIP_TRY(hipMemsetAsync(e->pos_table, 0, (size_t)c.max_positions * D * e->esz, s));
+    } else if (name == "decoder.rope.cos" || name == "decoder.rope.sin") {
+        // host-built rotary tables [max_positions][head_dim / 2] (parler_tts_amd/weights.rope_tables: the oracle's formula)
+        if (!e->v_rope) return fail(PTTS_E_INVALID, "%s: the engine was not created with the rotary variant", cname);
+        if (ndim != 2 || shape[0] < c.max_positions || shape[1] != PTTS_HEAD_DIM / 2) return fail(PTTS_E_INVALID, "%s: bad shape", cname);
+        rc = load_f32(e, name == "decoder.rope.cos" ? &e->rope_cos : &e->rope_sin, (size_t)shape[0] * shape[1], data, shape, ndim, s);
     } else if (parse_idx(name, "decoder.model.decoder.layers.", &idx, &rest)) {
         if (idx < 0 || idx >= c.layers) return fail(PTTS_E_INVALID, "%s: layer out of range", cname);
         DecLayer& w = e->layers[idx];
@@ -984,7 +1047,8 @@ int ptts_load_tensor(ptts_engine* e, const char* cname, const float* data, const
         else if (rest == "encoder_attn.k_proj.weight") rc = load_packed(e, &w.ckv, 2 * D, D, 0, 1, data, shape, ndim, D, s);
         else if (rest == "encoder_attn.v_proj.weight") rc = load_packed(e, &w.ckv, 2 * D, D, D, 1, data, shape, ndim, D, s);
         else if (rest == "encoder_attn.out_proj.weight") rc = load_packed(e, &w.co, D, D, 0, 1, data, shape, ndim, D, s);
-        else if (rest == "fc1.weight") rc = load_packed(e, &w.fc1, F, D, 0, 1, data, shape, ndim, F, s);
+        else if (rest == "fc1.weight") rc = load_packed(e, &w.fc1, e->v_swiglu ? 2 * F : F, D, 0, 1, data, shape, ndim, F, s);
+        else if (rest == "fc1_up.weight" && e->v_swiglu) rc = load_packed(e, &w.fc1, 2 * F, D, F, 1, data, shape, ndim, F, s);
         else if (rest == "fc2.weight") rc = load_packed(e, &w.fc2, D, F, 0, 1, data, shape, ndim, D, s);
         else if (rest == "self_attn_layer_norm.weight") rc = load_f32(e, &w.ln1_g, D, data, shape, ndim, s);
         else if (rest == "self_attn_layer_norm.bias") rc = load_f32(e, &w.ln1_b, D, data, shape, ndim, s);
@@ -1035,6 +1099,17 @@ int ptts_load_tensor(ptts_engine* e, const char* cname, const float* data, const
         return PTTS_OK;  // tied T5 embedding alias
     } else known = false;
     if (!known) return fail(PTTS_E_INVALID, "unknown tensor name '%s'", cname);
+    if (rc == PTTS_OK && e->v_rms && name.size() > 15 && name.compare(name.size() - 15, 15, "layer_norm.bias") == 0 &&
+        name.compare(0, 8, "decoder.") == 0) {
+        // RMSNorm variant: no shift.  The bias tensors of the key layout are accepted and zeroed (folded c2 = 0)
+        float** dst = nullptr;
+        if (name == "decoder.model.decoder.layer_norm.bias") dst = &e->lnf_b;
+        else {
+            DecLayer& w = e->layers[idx];
+            dst = rest == "self_attn_layer_norm.bias" ? &w.ln1_b : (rest == "encoder_attn_layer_norm.bias" ? &w.ln2_b : &w.ln3_b);
+        }
+        HIP_TRY(hipMemsetAsync(*dst, 0, sizeof(float) * D, s));
+    }
     if (rc == PTTS_OK) { e->loaded.insert(name); e->fold_dirty = true; }
     if (rc == PTTS_OK) rc = leave_stream(e, stream, s);
     return rc;
@@ -1059,8 +1134,11 @@ int ptts_weights_ready(ptts_engine* e) {
                                "encoder_attn.out_proj.weight", "fc1.weight", "fc2.weight", "self_attn_layer_norm.weight",
                                "self_attn_layer_norm.bias", "encoder_attn_layer_norm.weight", "encoder_attn_layer_norm.bias",
                                "final_layer_norm.weight", "final_layer_norm.bias"};
-    for (int l = 0; l < c.layers; ++l)
+    for (int l = 0; l < c.layers; ++l) {
         for (const char* p : per_layer) { snprintf(buf, sizeof buf, "decoder.model.decoder.layers.%d.%s", l, p); need.push_back(buf); }
+        if (e->v_swiglu) { snprintf(buf, sizeof buf, "decoder.model.decoder.layers.%d.fc1_up.weight", l); need.push_back(buf); }
+    }
+    if (e->v_rope) { need.push_back("decoder.rope.cos"); need.push_back("decoder.rope.sin"); }
     if (c.t5_layers > 0) {
         need.push_back("text_encoder.shared.weight");
         need.push_back("text_encoder.encoder.final_layer_norm.weight");
@@ -1223,12 +1301,13 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
         if (need_rows > e->pf.rows) {
             HIP_TRY(hipStreamSynchronize(s));
             Work& w = e->pf;
-            for (void* p : {(void*)w.x, (void*)w.q, (void*)w.xstat, w.attn_frag, w.mlp_frag, w.x_frag, w.x_frag2})
+            for (void* p : {(void*)w.x, (void*)w.q, (void*)w.xstat, w.attn_frag, w.mlp_frag, w.x_frag, w.x_frag2, (void*)w.ffn_raw})
                 if (p) (void)hipFree(p);
             w = Work();
             const size_t D_ = c.hidden, F_ = c.ffn, R = need_rows;
             bool ok = hipMalloc((void**)&w.x, sizeof(float) * R * D_) == hipSuccess &&
-                      hipMalloc((void**)&w.q, sizeof(float) * R * D_) == hipSuccess &&
+                      hipMalloc((void**)&w.q, sizeof(float) * R * D_ * (e->v_rope ? 2 : 1)) == hipSuccess &&
+                      (!e->v_swiglu || hipMalloc((void**)&w.ffn_raw, sizeof(float) * R * 2 * F_) == hipSuccess) &&
                       hipMalloc((void**)&w.xstat, sizeof(float) * 2 * R * (D_ / 16 + 1)) == hipSuccess &&
                       hipMalloc(&w.attn_frag, e->esz * R * D_) == hipSuccess &&
                       hipMalloc(&w.mlp_frag, e->esz * R * F_) == hipSuccess &&
@@ -1620,6 +1699,9 @@ int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* byt
     else if (n == "self_bias") { *ptr = e->self_bias; *bytes = (int64_t)c.max_batch * e->s_cap * 4; }
     else if (n == "codec_latent") { *ptr = e->enc_latent; *bytes = (int64_t)e->enc_latent_bytes; }
     else if (n == "tok_in") { *ptr = e->tok_in; *bytes = rows * c.codebooks * 4; }
+#ifdef PTTS_STAMPS
+    else if (n == "stamps") { *ptr = e->stamps; *bytes = (int64_t)PTTS_STAMP_SLOTS * PTTS_STAMP_WGS * 8 * 8; }
+#endif
     else return fail(PTTS_E_INVALID, "unknown buffer '%s'", name);
     return PTTS_OK;
 }

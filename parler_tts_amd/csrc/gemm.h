@@ -56,6 +56,13 @@ struct GemmArgs {
     // EPI_QKV_SELF in a batched prefill chunk: row = b * npos + i is cache position pos0 + i of utterance b
     // (npos = 0: decode, row = utterance, position = state->pos)
     int npos = 0, pos0 = 0;
+    // decoder-op variants (extensions, configuration.py; no counterpart in the reference):
+    int rms = 0;                  // folded path: RMSNorm instead of LayerNorm - y = rsqrt(mean(x^2) + eps) * (x.W') (c2 is zero)
+    int rope_k = 0;               // EPI_QKV_SELF: the k segment goes, unrotated and in fp32, to out[row][D + n] (ldo >= 2 D) instead
+                                  // of the cache; rope_launch (misc.h) rotates q in place and appends the rotated k
+#ifdef PTTS_STAMPS
+    StampRef stamps = {nullptr, -1};
+#endif
 };
 
 hipError_t gemm_init();

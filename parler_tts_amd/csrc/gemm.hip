@@ -169,6 +169,11 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
                     break;
                 }
                 kv = seg - 1;
+                if (a.rope_k && seg == 1) {      // rotary variant: k leaves in fp32 next to q, the rope kernel appends it
+                    float4* o = reinterpret_cast<float4*>(a.out + (size_t)row * a.ldo + a.D + nn);
+                    *o = make_float4(v[0], v[1], v[2], v[3]);
+                    break;
+                }
             }
             int b, tok;
             if (a.epi == EPI_QKV_SELF) {
@@ -199,6 +204,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     typedef typename P::elem_t elem_t;
     typedef Tile<P> T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PTTS_STAMPS
+    // 0 realtime at entry, 1 cycles at entry, 2 every global load of the first burst issued (kernel arguments arrived, addresses
+    // computed), 3 every load of the burst landed (diagnostic-only vmcnt(0)), 4 MFMA loop done, 5 K-split hand-over + barrier
+    // done, 6 epilogue stores issued, 7 realtime at exit
+    unsigned long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const StampRef stref = a.stamps;
+    stv[0] = stamp_realtime();
+    stv[1] = stamp_cycles();
+#endif
     constexpr int KSTEP = P::KSTEP, EPL = P::EPL;
     constexpr int TILE = 64 * EPL;                       // elements per 1 KiB tile
     constexpr int KC = 256 * KI;                         // K chunk parked in LDS
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         }
         nb0 = (((id >> 4) << 3) + (id & 7)) * NB;
         hsel = (id >> 3) & 1;
-        if (nb0 * 16 >= a.N) return;            // padding blocks of the last group of 8
+        if (nb0 * 16 >= a.N) return;            // padding blocks of the last group of 8 (no stamp record: zeros)
     } else if (!STAGE && !FOLD && a.W2) {       // wide second role: 32-row workgroups, the look-ahead blocks follow the first role's
         const int ids1 = a.N / (16 * NB);
         if ((int)blockIdx.x >= ids1) {
@@ -308,6 +322,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // only for what it needs while the weights are still in flight.
     const int cend0 = cstep < ksteps ? cstep : ksteps;
     if (!STAGE) load_burst(w, cend0);
+#ifdef PTTS_STAMPS
+    stv[2] = stamp_cycles();
+    if (!STAGE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stv[3] = stamp_cycles(); }
+#endif
 
     for (int c0 = 0; c0 < ksteps; c0 += cstep) {
         const int cend = (c0 + cstep < ksteps) ? c0 + cstep : ksteps;
@@ -440,6 +458,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         }
     }
 
+#ifdef PTTS_STAMPS
+    stv[4] = stamp_cycles();
+#endif
     // ---- K-split reduction in fixed wave order, then the fused epilogue ----
     f32x4* redv = reinterpret_cast<f32x4*>(red);
     if (STAGE) __syncthreads();   // all B-fragment reads of the stage image have retired
@@ -465,6 +486,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         }
     }
     __syncthreads();
+#ifdef PTTS_STAMPS
+    stv[5] = stamp_cycles();
+#endif
     const bool gated = (a.epi == EPI_GATED_FRAG);
     const int items = gated ? 128 : NB * 64 * H2;
     for (int t = tid; t < items; t += NW * 64) {
@@ -483,8 +507,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                 sq += stat[((ww * 2 + h) * 2 + 1) * 16 + (ln & 15)];
             }
             const float invK = 1.0f / (float)K;
-            const float mean = sx * invK;
-            const float var = fmaxf(sq * invK - mean * mean, 0.f);
+            const float mean = a.rms ? 0.f : sx * invK;          // RMSNorm variant: no centring
+            const float var = a.rms ? sq * invK : fmaxf(sq * invK - mean * mean, 0.f);
             const float rstd = 1.0f / sqrtf(var + a.eps);
             s[0] = rstd * (s[0] - mean * c1v.x) + c2v.x;
             s[1] = rstd * (s[1] - mean * c1v.y) + c2v.y;
@@ -515,6 +539,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             }
         }
     }
+#ifdef PTTS_STAMPS
+    stv[6] = stamp_cycles();
+    stv[7] = stamp_realtime();
+    stamp_store(stref, stv);
+#endif
 }
 
 template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false>

@@ -54,3 +54,22 @@ hipError_t build_bias_segment_launch(const int* mask, float* bias, int B, int n,
 hipError_t rowmask_mul_launch(const float* x, const int* rowmask, float* y, int rows, int D, hipStream_t s);
 hipError_t t5_embed_launch(const long long* ids, const void* table, float* x, int rows, int D, int dtype, hipStream_t s);
 hipError_t rmsnorm_rows_launch(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s);
+
+// ---- decoder-op variants (extensions: configuration.py norm_type / position_embedding / mlp_type; nothing in the reference) ----
+// Rotary positions on the self-attention: qk [rows][ld] fp32 holds the scaled q of every row in columns [0, D) and its
+// unrotated k in [D, 2 D) (EPI_QKV_SELF with rope_k); pairs (i, i + 32) of every 64-wide head are rotated by the angle of
+// the row's cache position (decode: state->pos; prefill chunk: pos0 + row % npos), q in place, k into the paged cache.
+// cos / sin: [max_positions][32] fp32 (built by the host with the oracle's formula, so the tables are bit-identical).
+struct RopeArgs {
+    float* qk = nullptr;
+    int ld = 0, D = 0, H = 0, rows = 0;
+    KVPool pool = {};
+    int layer = 0;
+    const StepState* state = nullptr;
+    int npos = 0, pos0 = 0;
+    const float* cos_t = nullptr;
+    const float* sin_t = nullptr;
+};
+hipError_t rope_launch(const RopeArgs& a, int dtype, hipStream_t s);
+// gated MLP: raw [rows][2 F] fp32 = [gate | up] pre-activations -> silu(gate) * up as B fragments [(rows + 31) / 32][32 * F]
+hipError_t swiglu_frag_launch(const float* raw, void* ofrag, int rows, int F, int dtype, hipStream_t s);

@@ -502,6 +502,40 @@ __global__ void rmsnorm_rows_kernel(const float* x, const float* w, float* y, in
     for (int d = threadIdx.x; d < D; d += blockDim.x) y[(size_t)r * D + d] = w[d] * (x[(size_t)r * D + d] * rstd);
 }
 
+
+// ---- decoder-op variants (extensions; see misc.h) ----
+// one wave per (row, head): lane i < 32 owns the pair (i, i + 32).  Products and sums are kept as separate roundings
+// (no fma contraction), the order of the fp32 PyTorch statement in oracle/cpu_ref.py: a * cos - b * sin, b * cos + a * sin.
+template <typename P>
+__global__ __launch_bounds__(64) void rope_kernel(RopeArgs a) {
+    typedef typename P::elem_t elem_t;
+    const int h = blockIdx.x, row = blockIdx.y, i = threadIdx.x;
+    if (i >= PTTS_HEAD_DIM / 2) return;
+    int b, pos;
+    if (a.npos > 0) { b = row / a.npos; pos = a.pos0 + (row - b * a.npos); }
+    else { b = row; pos = a.state->pos; }
+    const float c = a.cos_t[(size_t)pos * (PTTS_HEAD_DIM / 2) + i], sn = a.sin_t[(size_t)pos * (PTTS_HEAD_DIM / 2) + i];
+    float* q = a.qk + (size_t)row * a.ld + h * PTTS_HEAD_DIM;
+    const float qa = q[i], qb = q[i + 32];
+    q[i] = __fsub_rn(__fmul_rn(qa, c), __fmul_rn(qb, sn));
+    q[i + 32] = __fadd_rn(__fmul_rn(qb, c), __fmul_rn(qa, sn));
+    const float* k = q + a.D;
+    const float ka = k[i], kb = k[i + 32];
+    elem_t* dst = reinterpret_cast<elem_t*>(a.pool.base) + a.pool.elem_off(b, a.layer, 0, h, pos);
+    dst[i] = to_elem<P>(__fsub_rn(__fmul_rn(ka, c), __fmul_rn(kb, sn)));
+    dst[i + 32] = to_elem<P>(__fadd_rn(__fmul_rn(kb, c), __fmul_rn(ka, sn)));
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void swiglu_frag_kernel(const float* __restrict__ raw, typename P::elem_t* __restrict__ of, int rows, int F) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * F) return;
+    const int r = (int)(idx / F), n = (int)(idx - (size_t)r * F);
+    const float g = raw[(size_t)r * 2 * F + n], u = raw[(size_t)r * 2 * F + F + n];
+    const float y = __fmul_rn(g / (1.0f + expf(-g)), u);          // F.silu(g) * u
+    of[(size_t)(r >> 5) * 32 * F + frag_off<P>(r & 31, n)] = to_elem<P>(y);
+}
+
 }  // namespace
 
 hipError_t embed_codebooks_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s) {
@@ -566,5 +600,21 @@ hipError_t t5_embed_launch(const long long* ids, const void* table, float* x, in
 }
 hipError_t rmsnorm_rows_launch(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s) {
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, s, x, w, y, D, eps);
+    return hipGetLastError();
+}
+
+hipError_t rope_launch(const RopeArgs& a, int dtype, hipStream_t s) {
+    if (a.rows <= 0 || a.H <= 0 || a.ld < 2 * a.D || !a.cos_t || !a.sin_t) return hipErrorInvalidValue;
+    dim3 grid(a.H, a.rows);
+    if (dtype == PTTS_BF16) hipLaunchKernelGGL(rope_kernel<PBF16>, grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(rope_kernel<PF32>, grid, dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t swiglu_frag_launch(const float* raw, void* ofrag, int rows, int F, int dtype, hipStream_t s) {
+    const size_t total = (size_t)rows * F;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == PTTS_BF16) hipLaunchKernelGGL(swiglu_frag_kernel<PBF16>, grid, dim3(256), 0, s, raw, (uint16_t*)ofrag, rows, F);
+    else hipLaunchKernelGGL(swiglu_frag_kernel<PF32>, grid, dim3(256), 0, s, raw, (float*)ofrag, rows, F);
     return hipGetLastError();
 }

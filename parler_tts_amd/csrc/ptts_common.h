@@ -146,3 +146,36 @@ __device__ inline float wave_max(float v) {
     v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
     return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
+
+// ---- diagnostic build only (-DPTTS_STAMPS, `make STAMPS=1` -> libparler_tts_hip_stamps.so; never the product library) ----
+// In-kernel clock stamps of wave 0 of every workgroup: where a decode-step launch spends its time (s_memtime: shader cycles)
+// and where it sits relative to its neighbours in the stream (s_memrealtime: one 100 MHz counter for the whole device).
+// Record of workgroup g of the launch in slot s: stamps[(s * PTTS_STAMP_WGS + g) * 8 + i], i = 0 realtime at entry, 1 .. 6
+// memtime at the kernel's named points (1 = entry), 7 realtime at exit.  Values leave only through this buffer.
+#define PTTS_STAMP_WGS 1024
+#define PTTS_STAMP_SLOTS 256
+#ifdef PTTS_STAMPS
+struct StampRef { unsigned long long* buf; int slot; };
+__device__ inline unsigned long long stamp_cycles() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ inline unsigned long long stamp_realtime() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ inline void stamp_store(const StampRef& r, const unsigned long long (&v)[8]) {
+    if (!r.buf || r.slot < 0 || r.slot >= PTTS_STAMP_SLOTS) return;
+    const unsigned g = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x != 0 || g >= PTTS_STAMP_WGS) return;
+    unsigned long long* d = r.buf + ((size_t)r.slot * PTTS_STAMP_WGS + g) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = v[i];
+}
+#endif

@@ -90,6 +90,7 @@ class HipEngine:
         c.t5_act = _ACT[t5.dense_act_fn]
         c.t5_eps = t5.layer_norm_epsilon
         c.max_batch, c.max_desc_len, c.max_prompt_len, c.max_length = max_batch, max_desc_len, max_prompt_len, max_length
+        c.dec_variant = 0 if codec_only else int(getattr(d, "variant_flags", 0))     # RMSNorm / RoPE / SwiGLU extensions
         if codec_only:   # a placeholder decoder: only ptts_dac_decode will be called on this handle
             c.hidden, c.layers, c.heads, c.ffn, c.vocab, c.max_positions = 64, 0, 1, 32, 16, 64
             c.prompt_vocab, c.enc_hidden, c.max_batch, c.max_desc_len, c.max_prompt_len, c.max_length = 16, 32, 1, 1, 0, 2
@@ -132,6 +133,14 @@ class HipEngine:
                 torch.cuda.synchronize(self.device)
                 staged.clear()
                 n = 0
+        if not self.codec_only and getattr(self.cfg.decoder, "position_embedding", "sinusoidal") == "rope":
+            from .weights import rope_tables
+
+            for nm, t in zip(("decoder.rope.cos", "decoder.rope.sin"), rope_tables(self.cfg.decoder)):
+                g = t.to(device=self.device, dtype=torch.float32).contiguous()
+                shape = (C.c_int64 * 2)(*g.shape)
+                _hip.check(self.lib.ptts_load_tensor(self.handle, nm.encode(), _ptr(g), shape, 2, _stream()))
+                staged.append(g)
         torch.cuda.synchronize(self.device)
         staged.clear()
         if not self.codec_only:
@@ -344,7 +353,11 @@ class DACModel:
         if channels < 1 or channels > 2:
             raise ValueError(f"Number of audio channels must be 1 or 2, but got {channels}")      # D:53-54
         if channels != 1:
-            raise ValueError("the DAC encoder's first convolution takes one channel")               # descript: Conv1d(1, d, 7)
+            # the reference's check (D:53-54) admits two channels and the descript encoder's first layer, Conv1d(1, d, 7), then
+            # raises torch's RuntimeError: the same exception type and message shape here
+            d0 = getattr(self.config, "encoder_hidden_size", 64)
+            raise RuntimeError(f"Given groups=1, weight of size [{d0}, 1, 7], expected input{list(input_values.shape)} to have 1 "
+                               f"channels, but got {channels} channels instead")
         if n_quantizers is not None and n_quantizers != self.config.num_codebooks:
             raise NotImplementedError("n_quantizers < num_codebooks is not on the generate() path")
         codes = self._engine().dac_encode(input_values[:, 0])
@@ -461,10 +474,7 @@ class ParlerTTSForConditionalGeneration:
         allowed = {"input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "encoder_outputs",
                    "prompt_hidden_states", "decoder_input_ids", "return_raw_ids", "input_values", "padding_mask",
                    "decoder_attention_mask", "_decoder_only"}
-        unsupported = set()
         for k in model_kwargs:
-            if k in unsupported:
-                raise NotImplementedError(f"`{k}` is a SURVEY 8(f) 'next' row")
             if k not in allowed:
                 raise ValueError(f"The following `model_kwargs` are not used by the model: ['{k}']")
         if gen.pad_token_id is None and gen.eos_token_id is not None:   # M:2432-2442
@@ -779,7 +789,11 @@ class ParlerTTSForConditionalGeneration:
         if self.phase_times is not None:
             self.phase_times["post_ms"] += (_tick() - t_post) * 1e3
         if gen.return_dict_in_generate:
-            return ModelOutput(sequences=values)
+            # M:2682-2684: the third-party loop's own output object with `.sequences` overwritten by the waveform.  That object
+            # is a Greedy/SampleEncoderDecoderOutput (transformers 4.3x): its other fields are None unless `output_scores` /
+            # `output_attentions` / `output_hidden_states` were asked for; this engine keeps no per-step scores, so they stay None
+            return ModelOutput(sequences=values, scores=None, encoder_attentions=None, encoder_hidden_states=None,
+                               decoder_attentions=None, cross_attentions=None, decoder_hidden_states=None)
         return values
 
 

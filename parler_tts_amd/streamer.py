@@ -10,6 +10,14 @@ un-delays the columns as they arrive (codebook k of frame f sits in column f + k
 dilated residual units and one tap of the transposed conv per block, divided by the block's stride), so with >= 10
 frames of context the chunked waveform equals the one-shot DACModel.decode (dac_wrapper/modeling_dac.py:98-134) of the
 whole utterance sample for sample.  Latency = context_frames codec frames (16 frames = 0.19 s at 86 frames/s).
+
+Finished rows: once a (utterance, codebook) row has emitted EOS the loop pads it, so from some frame on an utterance's
+frames hold a special id.  The reference drops such frames per utterance before it decodes (M:2668-2670) and zero-pads the
+shorter waveforms (M:2676-2680).  The streamer does the same per window: an utterance whose first special frame `fb` falls
+inside the window is decoded ALONE over [w0, fb) - its last valid frames then see the zero padding of the clip's end, as
+in the one-shot decode, not clamped pad ids - and its samples from fb on are zero.
+`num_return_sequences > 1` is not served (the reference interleaves the expanded rows, M:2600-2606 / M:2645: there is no
+per-utterance frame order to stream): `put` raises ValueError when the row count changes after the start column.
 """
 from __future__ import annotations
 
@@ -59,6 +67,8 @@ class AudioStreamer:
         v = value.detach().to("cpu")
         if v.dim() == 1:
             v = v[:, None]
+        if self.cols and v.shape[0] != self.cols[0].shape[0]:
+            raise ValueError("AudioStreamer does not serve num_return_sequences > 1 (the id rows were expanded after the start column)")
         for c in range(v.shape[1]):
             self.cols.append(v[:, c])
         self._emit(final=False)
@@ -95,19 +105,21 @@ class AudioStreamer:
             e1 = n if (final and avail <= self.play + self.ctx) else e0 + self.play
             w0, w1 = max(0, e0 - self.ctx), (e1 if e1 == n and final else min(n, e1 + self.ctx))
             codes = self._codes(w0, w1)
-            if bool((codes >= size).any()) or bool((codes < 0).any()):
-                # special ids (EOS / PAD tails of finished rows): the reference drops such frames per utterance in its
-                # sequential path (M:2668-2670); here they decode as silence-free padding is impossible - clamp to a valid id
-                # for the window and zero the samples of the affected frames afterwards
-                bad = ((codes >= size) | (codes < 0)).any(dim=1)                 # [B, frames]
-                codes = codes.clamp(0, size - 1)
-            else:
-                bad = None
-            wav = self.model.audio_encoder.decode(codes[None].to(self.model.device), [None]).audio_values[:, 0]
-            if bad is not None:
-                wav = wav.clone()
-                wav.view(wav.shape[0], -1, hop)[bad.to(wav.device)] = 0
-            chunk = wav[:, (e0 - w0) * hop:(e1 - w0) * hop].cpu()
+            W = w1 - w0
+            special = ((codes >= size) | (codes < 0)).any(dim=1)                       # [B, frames]
+            # first special frame of every utterance inside the window (W = none)
+            first_bad = torch.where(special.any(dim=1), special.float().argmax(dim=1), torch.full((codes.shape[0],), W))
+            whole = (first_bad == W).nonzero().flatten()
+            wav = torch.zeros(codes.shape[0], W * hop, dtype=torch.float32)
+            if whole.numel():
+                out = self.model.audio_encoder.decode(codes[whole][None].to(self.model.device), [None]).audio_values[:, 0]
+                wav[whole] = out.to("cpu", torch.float32)
+            for bidx in (first_bad < W).nonzero().flatten().tolist():
+                fb = int(first_bad[bidx])
+                if fb > 0:      # the utterance ends at fb: decoded alone, its tail sees the end of the clip
+                    out = self.model.audio_encoder.decode(codes[bidx:bidx + 1, :, :fb][None].to(self.model.device), [None]).audio_values[:, 0]
+                    wav[bidx, : fb * hop] = out[0].to("cpu", torch.float32)
+            chunk = wav[:, (e0 - w0) * hop:(e1 - w0) * hop].clone()
             self.emitted = e1
             self.chunks.append(chunk)
             last = final and e1 == n

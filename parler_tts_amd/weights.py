@@ -41,6 +41,17 @@ def sinusoid_table(num_positions: int, dim: int) -> torch.Tensor:
     return torch.from_numpy(tab.astype(np.float32))
 
 
+def rope_tables(cfg: ParlerTTSDecoderConfig, num_positions: int = 0):
+    """(cos, sin), each [positions, head_dim / 2] fp32, of the rotary-position VARIANT (configuration.py: an extension with no
+    counterpart in the reference): angle(pos, i) = pos * rope_theta^(-2 i / head_dim), every step in fp32.  The engine and the
+    fp32 PyTorch statement in oracle/cpu_ref.py both read these tables, so they rotate by bit-identical angles."""
+    hd = cfg.hidden_size // cfg.num_attention_heads
+    n = num_positions or cfg.max_position_embeddings
+    inv = torch.pow(torch.tensor(float(cfg.rope_theta), dtype=torch.float32), -torch.arange(0, hd, 2, dtype=torch.float32) / hd)
+    ang = torch.arange(n, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.cos(ang), torch.sin(ang)
+
+
 # ----------------------------------------------------------------------------------------------
 # key enumeration
 # ----------------------------------------------------------------------------------------------
@@ -62,6 +73,8 @@ def decoder_keys(cfg: ParlerTTSDecoderConfig) -> Dict[str, tuple]:
             keys[f"{q}{ln}.bias"] = (D,)
         keys[f"{q}fc1.weight"] = (F, D)
         keys[f"{q}fc2.weight"] = (D, F)
+        if getattr(cfg, "mlp_type", "gelu") == "swiglu":      # extension (configuration.py): the "up" matrix of the gated MLP
+            keys[f"{q}fc1_up.weight"] = (F, D)
     keys[f"{p}layer_norm.weight"] = (D,)
     keys[f"{p}layer_norm.bias"] = (D,)
     for k in range(K):

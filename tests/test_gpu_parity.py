@@ -368,11 +368,13 @@ def run_forced_long(name, dtype, batch_pad=0):
     return f, cfg, torch.stack(logits), own[: B0 * K, 1:].cpu().numpy().T
 
 
-@pytest.mark.parametrize("name", ["tinylong_greedy", "minilong_greedy"])
+@pytest.mark.parametrize("name", ["tinylong_greedy", "minilong_greedy", "minilong2580_greedy"])
 def test_fp32_long_horizon_against_the_reference(hip, name):
-    """L = 2580 (tiny shape: 41 KV pages, positions > 2048) and L = 512 (mini_v0.1 shape) runs of the REAL reference.
-    fp32 engine, teacher-forced: logits of the sampled steps (first, page boundaries, S > 1024, S > 2048, the last 8)
-    within 2e-4, and the engine's own argmax equal to the reference's at EVERY step whose top-2 margin is >= 5e-4."""
+    """L = 2580 (tiny shape: 41 KV pages, positions > 2048), L = 512 (mini_v0.1 shape) and L = 2580 at the mini_v0.1 shape
+    (`minilong2580_greedy`: 24 layers x 16 heads over all 41 KV pages - BASELINE configs[1]'s exact decoder at its full
+    horizon) runs of the REAL reference.  fp32 engine, teacher-forced: logits of the sampled steps (first, EVERY page
+    boundary the run crosses, S > 1024, S > 2048, the last 8) within 2e-4, and the engine's own argmax equal to the
+    reference's at EVERY step whose top-2 margin is >= 5e-4."""
     f, cfg, logits, own = run_forced_long(name, "fp32")
     d = np.abs(logits.numpy() - f["step_logits"])
     assert d.max() < 2e-4, (d.max(), d.reshape(d.shape[0], -1).max(1))
@@ -392,7 +394,8 @@ def _bf16_long_reference(name, f):
     if name.startswith("mini"):                      # minutes of CPU: written by oracle/gen_golden.py --only-bf16
         g, _ = load_case(name + "_bf16")
         assert np.array_equal(g["logit_steps"], f["logit_steps"])
-        return g["step_logits"], g["own"], g["margins"], float(np.abs(g["step_logits"] - g["step_logits_acc64"]).max())
+        spread = float(g["spread"]) if "spread" in g else float(np.abs(g["step_logits"] - g["step_logits_acc64"]).max())
+        return g["step_logits"], g["own"], g["margins"], spread
     _, meta = load_case(name)
     cfg, sd = state_dict_for(name, meta)
     desc, amask, prompt, pmask = case_inputs(f)
@@ -413,7 +416,8 @@ def _bf16_long_reference(name, f):
     return r["step_logits"].numpy(), r["own"].numpy(), torch.stack(margins).numpy(), spread
 
 
-@pytest.mark.parametrize("name,pad", [("tinylong_greedy", 0), ("minilong_greedy", 0), ("minilong_greedy", 30)])
+@pytest.mark.parametrize("name,pad", [("tinylong_greedy", 0), ("minilong_greedy", 0), ("minilong_greedy", 30),
+                                      ("minilong2580_greedy", 0), ("minilong2580_greedy", 30)])
 def test_bf16_long_horizon_against_the_bf16_restatement(hip, name, pad):
     """The benchmark precision (BASELINE configs[1]) held to the CPU restatement with the engine's rounding points, over the
     same long runs: logits within the bound of _bf16_bound (one bf16 ulp on the 2-layer shape, 2x the restatement's own
@@ -1456,6 +1460,55 @@ def test_long_description_long_prompt_and_page_crossings_fp32(hip):
     top2 = torch.topk(want, 2, dim=-1)[0]
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3
     assert torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe])
+
+
+VARIANTS = [dict(norm_type="rms_norm"), dict(position_embedding="rope"), dict(mlp_type="swiglu"),
+            dict(norm_type="rms_norm", position_embedding="rope", mlp_type="swiglu")]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "+".join(sorted(v.values())))
+def test_decoder_op_variants_unpinned_by_the_reference(hip, dtype, variant):
+    """RMSNorm / rotary positions / SwiGLU as decoder variants (configuration.py extensions for the random-init scaled decoder,
+    SURVEY.md 8f.4).  UNPINNED BY THE REFERENCE: its decoder has LayerNorm with bias, additive sinusoids and a GELU MLP and no
+    switch, so the checker is the plain fp32 PyTorch statement of the same ops in oracle/cpu_ref.decoder_forward - each flag
+    alone and all three together, ragged masks, a prompt that crosses into a second KV page (rotation angles of the prefill
+    chunk rows AND of the decode steps), teacher-forced: fp32 engine logits within 2e-4 and the argmax equal wherever the
+    statement decides clearly; bf16 engine within bf16 noise of it."""
+    from parler_tts_amd.configuration import tiny_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = tiny_config(**variant)
+    sd = synthetic_state_dict(cfg, seed=11, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+    if "mlp_type" in variant:
+        assert "decoder.model.decoder.layers.0.fc1_up.weight" in sd
+    got, want, ref_ids, got_raw = _oracle_vs_engine(cfg, sd, dtype, B=3, T=10, P=60, L=21, seed=12, steps=20, ragged=True)
+    if dtype == "fp32":
+        assert (got - want).abs().max() < 2e-4, (got - want).abs().max()
+        top2 = torch.topk(want, 2, dim=-1)[0]
+        safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+        assert safe.float().mean() > 0.3 and torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe])
+    else:
+        assert (got - want).abs().max() < 0.08, (got - want).abs().max()
+        top2 = torch.topk(want, 2, dim=-1)[0]
+        safe = (top2[..., 0] - top2[..., 1]) > 0.05
+        assert (got.argmax(-1)[safe] == want.argmax(-1)[safe]).float().mean() > 0.9
+
+
+def test_decoder_op_variants_scaled_config_all_three_bf16(hip):
+    """BASELINE configs[4]'s decoder (d_model 1536, 24 heads, ffn 6144; cut to 4 layers for the CPU statement) with all three
+    variants on, batch 8, bf16 and fp32 (rows wider than the LDS stage: folded RMSNorm in both), against the fp32 PyTorch
+    statement.  Unpinned by the reference, as above."""
+    from parler_tts_amd.configuration import scaled_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = scaled_config()
+    cfg.decoder.num_hidden_layers = 4
+    cfg.decoder.norm_type, cfg.decoder.position_embedding, cfg.decoder.mlp_type = "rms_norm", "rope", "swiglu"
+    sd = synthetic_state_dict(cfg, seed=5, never_eos=True, ln_jitter=0.1, parts=("decoder",))
+    for dtype, tol in (("fp32", 5e-4), ("bf16", 0.1)):
+        got, want, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=8, T=40, P=16, L=9, seed=3, steps=8)
+        assert (got - want).abs().max() < tol, (dtype, (got - want).abs().max())
 
 
 def test_long_description_bf16_lookahead_off_path(hip):

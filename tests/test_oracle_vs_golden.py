@@ -202,7 +202,7 @@ def test_num_return_sequences_matches_reference():
     assert np.array_equal(codes.numpy(), f["codes"])
 
 
-@pytest.mark.parametrize("name", ["tinylong_greedy", "minilong_greedy"])
+@pytest.mark.parametrize("name", ["tinylong_greedy", "minilong_greedy", "minilong2580_greedy"])
 def test_long_horizon_fixtures_pin_the_oracle(name):
     """Depth: the reference run over 2580 (tiny shape) / 512 (mini_v0.1 shape) columns.  The fp32 restatement, teacher-
     forced along the reference's raw ids, reproduces the sampled-step logits (incl. the last 8 steps, S > 2048 on tiny) and
@@ -217,6 +217,10 @@ def test_long_horizon_fixtures_pin_the_oracle(name):
     # how often the reference's own argmax is closer than 1e-4 to a tie over the whole horizon (documented, not a bound)
     close = (f["margins"][free] < 1e-4).mean()
     assert close < 0.01
+    if name == "minilong2580_greedy":        # the benchmark's horizon: a logit sample at EVERY KV page the run crosses
+        pages = {int(s_) for s_ in range(58, L - 1, 64)}
+        assert pages <= set(int(x) for x in steps) and {1024, 2048, L - 2} <= set(int(x) for x in steps)
+        assert f["raw_ids"].shape == (2 * 9, 2580)
     if name.startswith("mini"):
         return
     cfg, sd = state_dict_for(name, meta)
@@ -280,6 +284,23 @@ def test_dac_decode_matches_transformers_dac(name):
     assert np.sqrt((err ** 2).mean()) < 1e-5
     rms = float(np.sqrt((f["wav"] ** 2).mean()))
     assert 0.05 < rms < 0.95, "fixture must not be saturated / silent"
+
+
+def test_dac_decode_oracle_at_300_frames_matches_transformers_dac():
+    """the production-size codec fixture (oracle/gen_golden.py --only-dac-long): the CPU restatement reproduces the
+    transformers DacModel waveform at 300 frames too (first utterance; the GPU test compares both and the 2571-frame clip)"""
+    f, _ = load_case("dac_mini_f300")
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=int(f["seed"]), parts=("audio_encoder",))
+    # the second utterance's first 96 frames, decoded from a 112-frame prefix (the codec is local: receptive field ~10 frames)
+    codes = torch.from_numpy(f["codes"])[1:2, :, :112]
+    n = 96 * cfg.audio_encoder.hop_length
+    wav = cpu_ref.dac_decode(cfg, sd, codes[None])
+    err = wav.numpy().reshape(-1)[:n] - f["wav"][1].reshape(-1)[:n]
+    assert np.sqrt((err ** 2).mean()) < 1e-5 and np.abs(err).max() < 1e-4
+    g, _ = load_case("dac_mini_f2571")
+    assert int(g["n_samples"]) == 2571 * cfg.audio_encoder.hop_length and g["wav_stride"].shape[1] * int(g["stride"]) >= int(g["n_samples"])
+    assert g["block_sums"].shape[1] == -(-int(g["n_samples"]) // int(g["block"])) and int(g["n_windows"]) == 4
 
 
 def test_codes_to_waveform_sequential_path():

@@ -101,6 +101,15 @@ def main():
     st = _hip.PttsState()
     _hip.check(lib.ptts_get_state(h, C.byref(st), None))
     print(f"done: cur_len={st.cur_len} pos={st.pos} layers={NL} B={B} D={D}", flush=True)
+    if os.environ.get("PTTS_STAMPS_OUT"):     # diagnostic library (make stamps; PTTS_HIP_LIB=...): in-kernel clock stamps of the LAST step
+        ptr, nbytes = C.c_void_p(), C.c_int64()
+        _hip.check(lib.ptts_debug_buffer(h, b"stamps", C.byref(ptr), C.byref(nbytes)))
+        host = np.empty(nbytes.value // 8, np.uint64)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), ptr, nbytes.value, 2) == 0
+        host = host.reshape(-1, 1024, 8)
+        used = int((host[:, :, 0] != 0).any(axis=1).sum())
+        np.save(os.environ["PTTS_STAMPS_OUT"], host[:used])
+        print(f"stamps: {used} launch slots saved", flush=True)
     lib.ptts_destroy(h)
 
 
