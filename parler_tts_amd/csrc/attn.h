@@ -12,6 +12,8 @@ struct AttnArgs {
     int len_from_state = 0;       // 1: keys = state->pos + 1 (self attention, after this step's append)
     const StepState* state = nullptr;
     const float* bias = nullptr;  // additive mask [B][ld_bias] (0 / finfo.min) or null
+    const int* bias_flag = nullptr;  // single-page kernel: device word, 0 = `bias` holds no finfo.min at all (an all-ones mask): the kernel
+                                     // then skips the mask loads (a quarter of its load instructions); null = always load
     int ld_bias = 0;
     int s_cap = 0;                // LDS score capacity (>= max keys, multiple of 4)
     void* ofrag = nullptr;        // output in B-fragment order, feature count D

@@ -75,30 +75,70 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     float* wred = red + NWAVES * 64;                              // [NWAVES] cross-wave scalars
     int* pages = reinterpret_cast<int*>(wred + NWAVES);           // [max_blocks] this utterance's page ids
 
+    // every kernel-argument field of the prologue in ONE scalar-memory round trip (hipcc otherwise fetches them piecemeal)
+    asm volatile("" :: "s"(a.q), "s"(a.pool.base), "s"(a.pool.block_table), "s"(a.state), "s"(a.bias), "s"(a.unfinished), "s"(a.ofrag),
+                 "s"(a.ldq), "s"(a.layer), "s"(a.len), "s"(a.len_from_state), "s"(a.pool.max_blocks), "s"(a.pool.H), "s"(a.pool.n_pages),
+                 "s"(a.rows_per_utt), "s"(a.alive_k), "s"(a.alive_b), "s"(a.lnfix_qkv), "s"(a.s_cap), "s"(a.D));
     const int h = blockIdx.x, b = blockIdx.y;                    // b: query row; bu: the utterance whose cache it reads
     const int bu = b / a.rows_per_utt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    int S = a.len_from_state ? (a.state->pos + 1) : a.len;
-    const int pos_append = S - 1;                                 // cache position of this step's own k / v (append-only cache)
-    if (a.unfinished) {                                           // finished utterance: one key instead of the whole cache
-        const int* u = a.unfinished + (bu % a.alive_b) * a.alive_k;
-        int alive = 0;
-        for (int k = 0; k < a.alive_k; ++k) alive |= u[k];
-        if (!alive) S = 1;
-    }
     const int tt = lane / LPT, c = lane % LPT;                    // token-in-tile, 16-byte chunk of the row
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
-
-    float q[EPL];
-    const float* bias = a.bias ? a.bias + (size_t)bu * a.ld_bias : nullptr;
-    // page ids once into LDS: KV addresses then depend on no global load
     const bool ident = a.pool.block_table == nullptr;      // identity table: page of block i is bu * max_blocks + i
-    if (!ident)
-        for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[bu * a.pool.max_blocks + i];
     const int page0 = bu * a.pool.max_blocks;
     const size_t page_elems = a.pool.page_elems();       // stride between two pages inside this head's K (or V) slab
     const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
+
+    // The loads that feed the context length and the query are stated FIRST, so that they are older than the key tiles
+    // below (vector-memory results return in issue order: a flag queued behind an HBM tile would wait for it).
+    int pos_ld = 0;
+    if (a.len_from_state) pos_ld = scalar_load_int(&a.state->pos);
+    int uflag[16];               // scalar loads too (the flag array is over-allocated by 16 ints: engine.hip)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) uflag[k] = 1;
+    if (a.unfinished) {
+        const int* u = a.unfinished + (bu % a.alive_b) * a.alive_k;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) uflag[k] = scalar_load_int(u + k);
+    }
+    float q[EPL];
+    if (!a.lnfix_qkv) {
+        const float* qp = a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) q[j] = qp[j];
+    }
+    // Early K burst: under the identity page table the addresses of the wave's first UNR key tiles depend on nothing but
+    // kernel arguments, so they go out BEFORE the context length is known (state->pos and the finished-utterance flags are
+    // dependent trips to memory: 1.5 us from kernel entry to the first K load in the round-3 stamps).  Token indices are
+    // clamped to the utterance's page run (capacity) instead of S - 1; rows at or past S may hold anything - their scores
+    // are never written (score_burst tests tok < S) and no V tile is requested before S is known.
+    const bool early = ident && !a.lnfix_qkv;
+    raw_t bufA[UNR], bufB[UNR];
+    if (early) {
+        const int cap = a.pool.max_blocks * PTTS_PAGE_TOKENS - 1;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int tok = (w + u * NWAVES) * TPW + tt;
+            if (tok > cap) tok = cap;
+            const raw_t* src = reinterpret_cast<const raw_t*>(pool + (size_t)(page0 + (tok >> 6)) * page_elems + head_off +
+                                                              (size_t)(tok & 63) * PTTS_HEAD_DIM);
+            bufA[u] = __builtin_nontemporal_load(src);
+        }
+    }
+    int S = a.len_from_state ? (pos_ld + 1) : a.len;
+    const int pos_append = S - 1;                                 // cache position of this step's own k / v (append-only cache)
+    if (a.unfinished) {                                           // finished utterance: one key instead of the whole cache
+        int alive = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) alive |= k < a.alive_k ? uflag[k] : 0;
+        if (!alive) S = 1;
+    }
+
+    const float* bias = a.bias ? a.bias + (size_t)bu * a.ld_bias : nullptr;
+    // page ids once into LDS: KV addresses then depend on no global load
+    if (!ident)
+        for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[bu * a.pool.max_blocks + i];
     if (a.lnfix_qkv) {
         // Look-ahead QKV: `a.q` is the raw product x.Wqkv'^T this head's slices of which still need the LayerNorm of the
         // folded projection, rstd * (raw - mean * c1) + c2, from the per-block statistics the producing launch wrote.
@@ -130,10 +170,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) q[j] = qs[c * EPL + j];
     } else {
-        const float* qp = a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) q[j] = qp[j];
-        if (!ident) __syncthreads();          // the page ids are in LDS
+        if (!ident) __syncthreads();          // the page ids are in LDS (q was requested at kernel entry)
     }
     const int ntiles = (S + TPW - 1) / TPW;
 
@@ -166,10 +203,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     };
 
     // ---------------- pass 1: scores, bursts double-buffered in registers ----------------
-    raw_t bufA[UNR], bufB[UNR];
     {
         int t0 = w;
-        load_burst(bufA, t0, 0);
+        if (!early) load_burst(bufA, t0, 0);
 #ifdef PTTS_STAMPS
         stv[2] = stamp_cycles();
 #endif
@@ -302,6 +338,10 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     stv[0] = stamp_realtime();
     stv[1] = stamp_cycles();
 #endif
+    // every kernel-argument field in ONE scalar-memory round trip (see attn_decode_kernel)
+    asm volatile("" :: "s"(a.q), "s"(a.pool.base), "s"(a.pool.block_table), "s"(a.bias), "s"(a.bias_flag), "s"(a.ofrag), "s"(a.lnfix_stat), "s"(a.lnfix_c1),
+                 "s"(a.lnfix_c2), "s"(a.ldq), "s"(a.layer), "s"(a.len), "s"(a.pool.max_blocks), "s"(a.pool.H), "s"(a.pool.n_pages),
+                 "s"(a.rows_per_utt), "s"(a.lnfix_blocks), "s"(a.ld_bias), "s"(a.D), "s"(H));
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
     const int bu = b / a.rows_per_utt;          // query row b reads utterance bu's page and mask row
@@ -316,8 +356,10 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     // 2*NT loads are in flight together; tiles past S are masked out of the arithmetic instead
     raw_t kb[NT], vb[NT];
     float bs[NT];
-    const bool has_bias = a.bias != nullptr;
-    const float* brow = has_bias ? a.bias + (size_t)bu * a.ld_bias : a.q;   // a.q: any readable floats, result unused
+    // an all-ones description mask (every equal-length batch) leaves the bias all zero: build_bias_kernel says so in a device
+    // word, read through the scalar cache; the uniform branch below then drops the NT mask loads of every lane
+    const bool has_bias = a.bias != nullptr && (a.bias_flag == nullptr || scalar_load_int(a.bias_flag) != 0);
+    const float* brow = a.bias + (size_t)bu * a.ld_bias;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         int tok = u * TPW + tt;
@@ -340,11 +382,14 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
         }
     }
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        int tok = u * TPW + tt;
-        tok = tok < S ? tok : S - 1;
-        const float bv = brow[tok];
-        bs[u] = has_bias ? bv : 0.f;
+    for (int u = 0; u < NT; ++u) bs[u] = 0.f;
+    if (has_bias) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            int tok = u * TPW + tt;
+            tok = tok < S ? tok : S - 1;
+            bs[u] = brow[tok];
+        }
     }
     // look-ahead query: statistics partials of row b (one 16-column block per lane) and this lane's c1 / c2 slice
     const bool lnfix = a.lnfix_stat != nullptr;
@@ -363,6 +408,11 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
             fc2[j] = a.lnfix_c2[h * PTTS_HEAD_DIM + c * EPL + j];
         }
     }
+#ifdef PTTS_STAMPS
+    stv[2] = stamp_cycles();                    // every load issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stv[3] = stamp_cycles();                    // ... and landed (diagnostic build only)
+#endif
     // hipcc otherwise sinks the V loads below the score arithmetic; an empty asm use pins every load above this point
 #pragma unroll
     for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(kb[u]));

@@ -150,6 +150,7 @@ struct ptts_engine {
     float *self_bias = nullptr, *cross_bias = nullptr;
     int s_cap = 0;
     bool has_self_bias = false;
+    int* cross_masked = nullptr;        // device word: the description mask of the current call holds a zero (build_bias_kernel)
     int *tok_in = nullptr, *unfinished = nullptr;
     bool skip_finished = true;          // PTTS_NO_SKIP_FINISHED=1: finished utterances keep streaming their cache (A/B, tests)
     long long* force = nullptr;
@@ -469,7 +470,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294)
             a = AttnArgs();
             a.q = wk.q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
-            a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS;
+            a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS; a.bias_flag = e->cross_masked;
             a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = wk.attn_frag; a.D = D;
             a.no_page_kernel = e->no_page_kernel ? 1 : 0;
             a.rows_per_utt = npos > 0 ? npos : 1;
@@ -966,9 +967,10 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->probs, sizeof(float) * rows * K * e->Vp);
     A(e->self_bias, sizeof(float) * Bm * e->s_cap);
     A(e->cross_bias, sizeof(float) * Bm * e->cross_blocks * PTTS_PAGE_TOKENS);
+    A(e->cross_masked, sizeof(int) * 4);
     A(e->enc_h, sizeof(float) * ((size_t)Bm * cfg->max_desc_len + 32) * D);
     A(e->tok_in, sizeof(int) * rows * K);
-    A(e->unfinished, sizeof(int) * rows * K);
+    A(e->unfinished, sizeof(int) * (rows * K + 16));     // + 16: the attention kernel reads 16 flags from an utterance's first one
     A(e->force, sizeof(long long) * rows * K);
     A(e->state, sizeof(StepState));
     if (cfg->t5_layers > 0) {
@@ -1226,7 +1228,7 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     e->pattern = (const long long*)pattern; e->raw_ids = (long long*)raw_ids; e->prompt_ids = (const long long*)prompt_ids;
     const int D = c.hidden, M = B_eff * T;
     // additive masks (M:870-879)
-    if (T > 0) HIP_TRY(build_bias_launch(attention_mask, e->cross_bias, B_eff, T, e->cross_blocks * PTTS_PAGE_TOKENS, s));
+    if (T > 0) HIP_TRY(build_bias_launch(attention_mask, e->cross_bias, B_eff, T, e->cross_blocks * PTTS_PAGE_TOKENS, s, e->cross_masked));
     e->has_self_bias = prompt_mask != nullptr || e->dec_mask != nullptr;
     if (e->has_self_bias)   // n_mask = 0 zero-fills (no prompt mask: every prompt key is attended)
         HIP_TRY(build_bias_launch(prompt_mask ? prompt_mask : e->dec_mask, e->self_bias, B_eff, prompt_mask ? P : 0, e->s_cap, s));

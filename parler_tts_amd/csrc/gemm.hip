@@ -108,11 +108,16 @@ __device__ inline void store_frag4<PF32>(float* of, int r32, int n, const float 
     for (int r = 0; r < 4; ++r) of[frag_off<PF32>(r32, n + r)] = y[r];
 }
 
-template <typename P>
-__device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x4 v1, const float4& xres, bool have_res) {
+// EPI_T / ACT_T >= 0: the epilogue (activation) is fixed at compile time.  The decode step's six projections run on instances
+// specialised this way: the generic instance carries every epilogue and activation behind run-time switches - 1900 of its 3300
+// instructions, 120 branches - and a launch that executes one path of it jumps across a 12 KB region of code that is cold in
+// the instruction cache at every launch (round-3 stamps: ~2200 cycles between the hand-over barrier and the last store).
+template <typename P, int EPI_T = -1, int ACT_T = -1>
+__device__ inline void epilogue(const GemmArgs& a, int epi, int row, int n, f32x4 v, f32x4 v1, const float4& xres, bool have_res) {
     // row: absolute output row; n: first of this lane's 4 consecutive output features
     typedef typename P::elem_t elem_t;
-    switch (a.epi) {
+    const int act = ACT_T >= 0 ? ACT_T : a.act;
+    switch (epi) {
         case EPI_ROWMAJOR: {
             float* o = a.out + (size_t)row * a.ldo + n;
             float s = a.rowmask ? (float)a.rowmask[row] : 1.0f;
@@ -121,7 +126,7 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
                 if (n + r >= a.N) break;
                 float y = v[r];
                 if (a.bias) y += a.bias[n + r];
-                y = act_apply(a.act, y);
+                y = act_apply(act, y);
                 if (a.rowmask) y *= s;
                 o[r] = y;
             }
@@ -150,8 +155,8 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
             float yv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float y = act_apply(a.act, v[r]);
-                if (a.epi == EPI_GATED_FRAG) y *= v1[r];
+                float y = act_apply(act, v[r]);
+                if (epi == EPI_GATED_FRAG) y *= v1[r];
                 yv[r] = y;
             }
             store_frag4<P>(of, row & 31, n, yv);
@@ -162,7 +167,7 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
             // n in [0, nseg*D): segment 0 of QKV_SELF is q (scaled, row-major); the rest go to the cache
             int seg = n / a.D, nn = n - seg * a.D;
             int kv = seg;
-            if (a.epi == EPI_QKV_SELF) {
+            if (epi == EPI_QKV_SELF) {
                 if (seg == 0) {
                     float4* o = reinterpret_cast<float4*>(a.out + (size_t)row * a.ldo + nn);
                     *o = make_float4(v[0] * a.scale, v[1] * a.scale, v[2] * a.scale, v[3] * a.scale);
@@ -176,9 +181,9 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
                 }
             }
             int b, tok;
-            if (a.epi == EPI_QKV_SELF) {
+            if (epi == EPI_QKV_SELF) {
                 if (a.npos > 0) { b = row / a.npos; tok = a.pos0 + (row - b * a.npos); }
-                else { b = row; tok = a.state->pos; }
+                else { b = row; tok = scalar_load_int(&a.state->pos); }     // scalar cache: no wait on the vector-memory queue
             } else { b = row / a.T; tok = row - b * a.T; }
             elem_t* c = reinterpret_cast<elem_t*>(a.pool.base) +
                         a.pool.elem_off(b, a.layer, kv, nn >> 6, tok) + (nn & 63);
@@ -189,8 +194,9 @@ __device__ inline void epilogue(const GemmArgs& a, int row, int n, f32x4 v, f32x
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD, int EPI_T = -1, int ACT_T = -1, int W2_T = -1>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
+    // EPI_T / ACT_T: see epilogue().  W2_T = 0: the launch has no second role (the look-ahead code is compiled out).
     // FOLD (fragment input, NB = 1): the fragments are the raw residual rows and W carries the LayerNorm gain.
     // Row statistics (sum x, sum x^2 over the bf16/fp32 values the MFMA consumes) are accumulated per lane on the
     // VALU from the B fragments while the weight tiles are still in flight, folded across the four k-groups of a
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     if (H2 == 1) {
         int id = blockIdx.x;
         const int ids1 = ((a.N / 16 + 7) / 8) * 16;
-        if (!STAGE && !FOLD && a.W2 && id >= ids1) {   // second role: the look-ahead product (uniform per workgroup)
+        if (W2_T != 0 && !STAGE && !FOLD && a.W2 && id >= ids1) {   // second role: the look-ahead product (uniform per workgroup)
             role2 = true;
             id -= ids1;
             a.W = a.W2; a.N = a.N2; a.K = a.K2;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         nb0 = (((id >> 4) << 3) + (id & 7)) * NB;
         hsel = (id >> 3) & 1;
         if (nb0 * 16 >= a.N) return;            // padding blocks of the last group of 8 (no stamp record: zeros)
-    } else if (!STAGE && !FOLD && a.W2) {       // wide second role: 32-row workgroups, the look-ahead blocks follow the first role's
+    } else if (W2_T != 0 && !STAGE && !FOLD && a.W2) {       // wide second role: 32-row workgroups, the look-ahead blocks follow the first role's
         const int ids1 = a.N / (16 * NB);
         if ((int)blockIdx.x >= ids1) {
             role2 = true;
@@ -249,6 +255,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             a.bias = nullptr; a.rowmask = nullptr; a.act = ACT_NONE; a.xfrag_out = nullptr; a.xstat = nullptr;
         }
     }
+    // this workgroup's epilogue: fixed by the instance, except for the second role's raw row-major product
+    const int epi = EPI_T >= 0 ? (role2 ? (int)EPI_ROWMAJOR : EPI_T) : a.epi;
     const int m0 = blockIdx.y * 32;
     const int K = a.K;
     const int ksteps = K / KSTEP;
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // read-modify-write at the end does not start with a cold load
     float4 xres = make_float4(0, 0, 0, 0);
     bool have_res = false;
-    if (a.epi == EPI_RESIDUAL && tid < NB * 64 * H2) {
+    if (epi == EPI_RESIDUAL && tid < NB * 64 * H2) {
         const int ln = tid & 63, hh = H2 == 2 ? ((tid >> 6) & 1) : hsel, ii = H2 == 2 ? (tid >> 7) : (tid >> 6);
         const int row = m0 + 16 * hh + (ln & 15), n = (nb0 + ii) * 16 + 4 * (ln >> 4);
         if (row < a.M && n < a.N) { xres = *reinterpret_cast<const float4*>(a.out + (size_t)row * a.ldo + n); have_res = true; }
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #ifdef PTTS_STAMPS
     stv[5] = stamp_cycles();
 #endif
-    const bool gated = (a.epi == EPI_GATED_FRAG);
+    const bool gated = (epi == EPI_GATED_FRAG);
     const int items = gated ? 128 : NB * 64 * H2;
     for (int t = tid; t < items; t += NW * 64) {
         const int ln = t & 63, h = H2 == 2 ? ((t >> 6) & 1) : 0, i = gated ? 0 : (H2 == 2 ? (t >> 7) : (t >> 6));
@@ -516,8 +524,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             s[3] = rstd * (s[3] - mean * c1v.w) + c2v.w;
         }
         const int n = gated ? blockIdx.x * 16 + 4 * (ln >> 4) : (nb0 + i) * 16 + 4 * (ln >> 4);
-        if (row < a.M) epilogue<P>(a, row, n, s, s1, xres, have_res && t == tid);
-        if (!STAGE && !FOLD && a.xstat && a.epi == EPI_RESIDUAL) {
+        if (row < a.M) {
+            if (EPI_T >= 0 && role2) epilogue<P, EPI_ROWMAJOR, ACT_NONE>(a, EPI_ROWMAJOR, row, n, s, s1, xres, false);
+            else epilogue<P, EPI_T, ACT_T>(a, epi, row, n, s, s1, xres, have_res && t == tid);
+        }
+        if (!STAGE && !FOLD && a.xstat && epi == EPI_RESIDUAL) {
             // partial LayerNorm statistics of the rows just written, over this block's 16 columns, on the values the
             // weight dtype will hold (so that a consumer's mean subtraction matches what its MFMA multiplied)
             float ps = 0.f, pq = 0.f;
@@ -546,7 +557,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #endif
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false, int EPI_T = -1, int ACT_T = -1, int W2_T = -1>
 hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int KC = 256 * KI;
     constexpr int PAD = 16 / (int)sizeof(typename P::elem_t);
@@ -558,7 +569,7 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     if (H2 == 1) grid.x = ((grid.x + 7) / 8) * 16;     // groups of 8 blocks x 2 halves
     if (H2 == 1 && !STAGE && !FOLD && a.W2) grid.x += ((a.N2 / 16 + 7) / 8) * 16;   // + the look-ahead role
     if (H2 == 2 && !STAGE && !FOLD && a.W2) grid.x += a.N2 / (16 * NB);              // + the look-ahead role, 32-row workgroups
-    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD>;
+    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD, EPI_T, ACT_T, W2_T>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -586,6 +597,20 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     // few feature blocks and more than 16 live rows: one 16-row half per workgroup doubles the busy CUs
     // (with a second role the half-split grid is used for every M: the arithmetic must not depend on the batch size)
     const bool halves = a.N <= 2048 && (a.M > 16 || a.W2) && a.epi != EPI_GATED_FRAG && !(a.W2 && a.wide2);
+    // ---- the decode step's projections on instances with a compile-time epilogue (PTTS_GEMM_GENERIC=1: the generic ones, A/B) ----
+    static const bool generic_only = getenv("PTTS_GEMM_GENERIC") != nullptr;
+    if (!generic_only && !a.force_whole && !a.bias && !a.rowmask) {
+        if (a.fold && !a.W2 && nw == 8 && !(halves)) {          // folded, 32-row workgroups, K <= 2048 (bf16) / 1024 (fp32)
+            if (a.epi == EPI_QKV_SELF) return launch_one<P, 8, 1, false, 1, 2, true, EPI_QKV_SELF, ACT_NONE, 0>(a, stream);
+            if (a.epi == EPI_ACT_FRAG && a.act == ACT_GELU) return launch_one<P, 8, 1, false, 1, 2, true, EPI_ACT_FRAG, ACT_GELU, 0>(a, stream);
+            if (a.epi == EPI_ROWMAJOR && a.act == ACT_NONE) return launch_one<P, 8, 1, false, 1, 2, true, EPI_ROWMAJOR, ACT_NONE, 0>(a, stream);
+        }
+        if (!a.fold && halves && a.epi == EPI_RESIDUAL) {        // residual projections on the half-split grid
+            if (a.W2 && nw == 8) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, -1>(a, stream);
+            if (!a.W2 && nw == 8) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);
+            if (!a.W2 && nw == 16) return launch_one<P, 16, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);
+        }
+    }
     if (a.fold) {
         // Round 1 kept the half-split folded instance out of the product path because it was the one configuration
         // that stayed non-repeatable with two processes on the GPU; its K-split hand-over was an inline-asm ds_write

@@ -49,7 +49,8 @@ hipError_t select_launch(const SelectArgs& a, hipStream_t s);
 hipError_t advance_launch(StepState* st, const int* unfinished, int rows, int L, hipStream_t s);
 hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,
                               int L, int col, hipStream_t s);
-hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s);
+// any_masked (optional device word): set to 1 iff the mask holds a zero, i.e. the bias holds a finfo.min (else 0)
+hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s, int* any_masked = nullptr);
 hipError_t build_bias_segment_launch(const int* mask, float* bias, int B, int n, int ld_bias, int offset, hipStream_t s);
 hipError_t rowmask_mul_launch(const float* x, const int* rowmask, float* y, int rows, int D, hipStream_t s);
 hipError_t t5_embed_launch(const long long* ids, const void* table, float* x, int rows, int D, int dtype, hipStream_t s);

@@ -453,12 +453,15 @@ __global__ void init_tokens_kernel(const long long* raw_ids, const long long* pa
 }
 
 // additive masks: 0 where attended, finfo.min where not (masked_fill semantics of the HF helpers, M:870-879)
-__global__ void build_bias_kernel(const int* mask, float* bias, int B, int n_mask, int ld_bias) {
+__global__ void build_bias_kernel(const int* mask, float* bias, int B, int n_mask, int ld_bias, int* any_masked) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * ld_bias) return;
     int b = i / ld_bias, s = i % ld_bias;
     float v = 0.f;
-    if (s < n_mask && mask[b * n_mask + s] == 0) v = -3.4028234663852886e38f;
+    if (s < n_mask && mask[b * n_mask + s] == 0) {
+        v = -3.4028234663852886e38f;
+        if (any_masked) *any_masked = 1;       // every writer stores the same value: no atomic needed (zeroed before the launch)
+    }
     bias[i] = v;
 }
 
@@ -585,9 +588,13 @@ hipError_t build_bias_segment_launch(const int* mask, float* bias, int B, int n,
     return hipGetLastError();
 }
 
-hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s) {
+hipError_t build_bias_launch(const int* mask, float* bias, int B, int n_mask, int ld_bias, hipStream_t s, int* any_masked) {
     int n = B * ld_bias;
-    hipLaunchKernelGGL(build_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, bias, B, n_mask, ld_bias);
+    if (any_masked) {
+        hipError_t e = hipMemsetAsync(any_masked, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(build_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, bias, B, n_mask, ld_bias, any_masked);
     return hipGetLastError();
 }
 hipError_t rowmask_mul_launch(const float* x, const int* rowmask, float* y, int rows, int D, hipStream_t s) {

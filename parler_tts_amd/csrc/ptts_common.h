@@ -112,6 +112,14 @@ struct StepState {
     int pad_;
 };
 
+// ---- loop state read through the scalar cache -----------------------------------------------------------------------
+// StepState.pos and the finished-row flags are written by the step's LAST kernels and only read by the following launches.
+// Read through a constant-address-space pointer they become scalar loads (s_load_dword: the scalar cache starts cold at every
+// launch, so the value is the current one), which neither wait for nor delay the vector-memory stream - a plain `state->pos`
+// compiles to a global_load + s_waitcnt vmcnt(0) in front of everything queued behind it.
+typedef const int __attribute__((address_space(4))) ptts_cint;
+__device__ inline int scalar_load_int(const int* p) { return *reinterpret_cast<ptts_cint*>(reinterpret_cast<uintptr_t>(p)); }
+
 // ---- K-split hand-over stores --------------------------------------------------------------------------------
 // MFMA accumulators go to LDS through PLAIN C++ stores, never through an `asm` statement: hipcc pads the gfx950
 // "XDL write VGPR -> LDS/VMEM/VALU read" hazard (8 wait states behind v_mfma_f32_16x16x32_bf16, 10 behind
