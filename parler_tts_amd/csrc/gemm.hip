@@ -33,7 +33,7 @@
 
 namespace {
 
-constexpr int U = 8;  // weight tiles in flight per wave
+constexpr int U_MAX = 8;  // weight tiles in flight per wave (per burst)
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -194,9 +194,15 @@ __device__ inline void epilogue(const GemmArgs& a, int epi, int row, int n, f32x
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD, int EPI_T = -1, int ACT_T = -1, int W2_T = -1>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD, int EPI_T = -1, int ACT_T = -1, int W2_T = -1, int TILES_T = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // EPI_T / ACT_T: see epilogue().  W2_T = 0: the launch has no second role (the look-ahead code is compiled out).
+    // TILES_T > 0 (fragment input): K / KSTEP == NW * TILES_T exactly - every wave streams TILES_T tiles in ONE burst with no
+    // per-tile guard, so the tile addresses are a compile-time stride apart (the guarded form recomputes each address with a
+    // multiply chain: ~450 scalar / vector instructions in front of the first load, in-kernel stamps: ~1 us of the launch).
+    constexpr int U = TILES_T > 0 ? TILES_T : U_MAX;
+    // (Pulling every kernel-argument field into SGPRs with one batched fetch at entry - an empty asm with "s" operands - was
+    // measured on these instances: decode pass 3722 -> 3779 ms, i.e. slower; hipcc's piecemeal fetches overlap with the first loads.)
     // FOLD (fragment input, NB = 1): the fragments are the raw residual rows and W carries the LayerNorm gain.
     // Row statistics (sum x, sum x^2 over the bf16/fp32 values the MFMA consumes) are accumulated per lane on the
     // VALU from the B fragments while the weight tiles are still in flight, folded across the four k-groups of a
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ks = ks0 + u * NW;
-                if (ks < cend) {
+                if (TILES_T > 0 || ks < cend) {
                     // the second role reads its first ksplit k-steps from xfrag_lo, the rest from xfrag
                     const bool lo = role2 && ks < a.ksplit;
                     const int kk = role2 && !lo ? ks - a.ksplit : ks;
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ks = ks0 + u * NW;
-            if (ks < cend) {
+            if (TILES_T > 0 || ks < cend) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i)
                     wt[u][i] = T::load_weights(Wp + ((size_t)(nb0 + i) * ksteps + ks) * TILE + lane * EPL);
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ks = ks0 + u * NW;
-                if (ks < cend) {
+                if (TILES_T > 0 || ks < cend) {
                     typename T::wfrag b0, b1;
                     if (STAGE) {
                         b0 = T::load_lds(xs, ld, (lane & 15), ks - c0, lane);
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #endif
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false, int EPI_T = -1, int ACT_T = -1, int W2_T = -1>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false, int EPI_T = -1, int ACT_T = -1, int W2_T = -1, int TILES_T = 0>
 hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int KC = 256 * KI;
     constexpr int PAD = 16 / (int)sizeof(typename P::elem_t);
@@ -569,7 +575,7 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     if (H2 == 1) grid.x = ((grid.x + 7) / 8) * 16;     // groups of 8 blocks x 2 halves
     if (H2 == 1 && !STAGE && !FOLD && a.W2) grid.x += ((a.N2 / 16 + 7) / 8) * 16;   // + the look-ahead role
     if (H2 == 2 && !STAGE && !FOLD && a.W2) grid.x += a.N2 / (16 * NB);              // + the look-ahead role, 32-row workgroups
-    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD, EPI_T, ACT_T, W2_T>;
+    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD, EPI_T, ACT_T, W2_T, TILES_T>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -600,15 +606,31 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     // ---- the decode step's projections on instances with a compile-time epilogue (PTTS_GEMM_GENERIC=1: the generic ones, A/B) ----
     static const bool generic_only = getenv("PTTS_GEMM_GENERIC") != nullptr;
     if (!generic_only && !a.force_whole && !a.bias && !a.rowmask) {
+        const int tiles = (ksteps % nw == 0) ? ksteps / nw : 0;      // exact fit: one unguarded burst of `tiles` tiles per wave
         if (a.fold && !a.W2 && nw == 8 && !(halves)) {          // folded, 32-row workgroups, K <= 2048 (bf16) / 1024 (fp32)
-            if (a.epi == EPI_QKV_SELF) return launch_one<P, 8, 1, false, 1, 2, true, EPI_QKV_SELF, ACT_NONE, 0>(a, stream);
-            if (a.epi == EPI_ACT_FRAG && a.act == ACT_GELU) return launch_one<P, 8, 1, false, 1, 2, true, EPI_ACT_FRAG, ACT_GELU, 0>(a, stream);
-            if (a.epi == EPI_ROWMAJOR && a.act == ACT_NONE) return launch_one<P, 8, 1, false, 1, 2, true, EPI_ROWMAJOR, ACT_NONE, 0>(a, stream);
+#define PTTS_FOLD_INST(EPI, ACT)                                                                                   \
+            do {                                                                                                    \
+                if (tiles == 4) return launch_one<P, 8, 1, false, 1, 2, true, EPI, ACT, 0, 4>(a, stream);          \
+                if (tiles == 8) return launch_one<P, 8, 1, false, 1, 2, true, EPI, ACT, 0, 8>(a, stream);          \
+                return launch_one<P, 8, 1, false, 1, 2, true, EPI, ACT, 0, 0>(a, stream);                           \
+            } while (0)
+            if (a.epi == EPI_QKV_SELF) PTTS_FOLD_INST(EPI_QKV_SELF, ACT_NONE);
+            if (a.epi == EPI_ACT_FRAG && a.act == ACT_GELU) PTTS_FOLD_INST(EPI_ACT_FRAG, ACT_GELU);
+            if (a.epi == EPI_ROWMAJOR && a.act == ACT_NONE) PTTS_FOLD_INST(EPI_ROWMAJOR, ACT_NONE);
+#undef PTTS_FOLD_INST
         }
         if (!a.fold && halves && a.epi == EPI_RESIDUAL) {        // residual projections on the half-split grid
+            // (the second role of the look-ahead launch streams 2 K: its workgroups need two bursts, so no exact-fit form)
             if (a.W2 && nw == 8) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, -1>(a, stream);
-            if (!a.W2 && nw == 8) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);
-            if (!a.W2 && nw == 16) return launch_one<P, 16, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);
+            if (!a.W2 && nw == 8) {
+                if (tiles == 4) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0, 4>(a, stream);
+                if (tiles == 8) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0, 8>(a, stream);
+                return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);
+            }
+            if (!a.W2 && nw == 16) {
+                if (tiles == 8) return launch_one<P, 16, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0, 8>(a, stream);
+                return launch_one<P, 16, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);
+            }
         }
     }
     if (a.fold) {
