@@ -75,10 +75,12 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     float* wred = red + NWAVES * 64;                              // [NWAVES] cross-wave scalars
     int* pages = reinterpret_cast<int*>(wred + NWAVES);           // [max_blocks] this utterance's page ids
 
+#ifndef PTTS_EXP_NO_ATTN_PIN
     // every kernel-argument field of the prologue in ONE scalar-memory round trip (hipcc otherwise fetches them piecemeal)
     asm volatile("" :: "s"(a.q), "s"(a.pool.base), "s"(a.pool.block_table), "s"(a.state), "s"(a.bias), "s"(a.unfinished), "s"(a.ofrag),
                  "s"(a.ldq), "s"(a.layer), "s"(a.len), "s"(a.len_from_state), "s"(a.pool.max_blocks), "s"(a.pool.H), "s"(a.pool.n_pages),
                  "s"(a.rows_per_utt), "s"(a.alive_k), "s"(a.alive_b), "s"(a.lnfix_qkv), "s"(a.s_cap), "s"(a.D));
+#endif
     const int h = blockIdx.x, b = blockIdx.y;                    // b: query row; bu: the utterance whose cache it reads
     const int bu = b / a.rows_per_utt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -338,17 +340,50 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     stv[0] = stamp_realtime();
     stv[1] = stamp_cycles();
 #endif
+#ifndef PTTS_EXP_NO_PAGE_PIN
     // every kernel-argument field in ONE scalar-memory round trip (see attn_decode_kernel)
     asm volatile("" :: "s"(a.q), "s"(a.pool.base), "s"(a.pool.block_table), "s"(a.bias), "s"(a.bias_flag), "s"(a.ofrag), "s"(a.lnfix_stat), "s"(a.lnfix_c1),
                  "s"(a.lnfix_c2), "s"(a.ldq), "s"(a.layer), "s"(a.len), "s"(a.pool.max_blocks), "s"(a.pool.H), "s"(a.pool.n_pages),
                  "s"(a.rows_per_utt), "s"(a.lnfix_blocks), "s"(a.ld_bias), "s"(a.D), "s"(H));
+#endif
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
     const int bu = b / a.rows_per_utt;          // query row b reads utterance bu's page and mask row
     const int S = a.len;
     const int tt = lane / LPT, c = lane % LPT;
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
-    const int page = a.pool.block_table ? a.pool.block_table[bu * a.pool.max_blocks] : bu * a.pool.max_blocks;
+    // Load order (vector-memory results return in issue order): the small L2-resident operands first - look-ahead statistics
+    // and fold constants, the query, the mask - then the 2 x NT key / value tiles; nothing is waited for until everything has
+    // been requested.  (Round 3 found the statistics loop BEHIND the tiles with an s_waitcnt vmcnt(0) per iteration, and the
+    // fold constants behind that: three serial memory round trips, 3500 of the launch's ~8500 cycles in front of the arithmetic.)
+    const bool lnfix = a.lnfix_stat != nullptr;
+    // every request below is UNCONDITIONAL straight-line code (indices clamped, pointers replaced by a readable dummy when the
+    // look-ahead is off): a load inside an `if` makes hipcc wait for it at the join, in front of everything stated later
+    const float* sp = lnfix ? a.lnfix_stat + ((size_t)(b >> 5) * a.lnfix_blocks * 32 + (b & 31)) * 2 : a.q;
+    const int nblk = lnfix ? a.lnfix_blocks : 1;
+    // one 16-column block per lane and request: two requests cover rows of up to 2048 features (wider rows: the loop further down)
+    const float2 p0 = *reinterpret_cast<const float2*>(sp + (size_t)(lane < nblk ? lane : nblk - 1) * (lnfix ? 64 : 0));
+    const float2 p1 = *reinterpret_cast<const float2*>(sp + (size_t)(lane + 64 < nblk ? lane + 64 : nblk - 1) * (lnfix ? 64 : 0));
+    const float* c1p = lnfix ? a.lnfix_c1 + h * PTTS_HEAD_DIM + c * EPL : a.q;
+    const float* c2p = lnfix ? a.lnfix_c2 + h * PTTS_HEAD_DIM + c * EPL : a.q;
+    f32x4 c1r[EPL / 4], c2r[EPL / 4];
+#pragma unroll
+    for (int j = 0; j < EPL / 4; ++j) {
+        c1r[j] = reinterpret_cast<const f32x4*>(c1p)[j];
+        c2r[j] = reinterpret_cast<const f32x4*>(c2p)[j];
+    }
+    float q[EPL];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL);
+#pragma unroll
+        for (int j = 0; j < EPL / 4; ++j) {
+            const f32x4 v = qp[j];
+            q[4 * j] = v[0]; q[4 * j + 1] = v[1]; q[4 * j + 2] = v[2]; q[4 * j + 3] = v[3];
+        }
+    }
+    // (a table entry is uniform per wave: read through the scalar cache, it does not join the vector-memory queue - a
+    // conditional vector load here made hipcc drain vmcnt in front of the tiles)
+    const int page = a.pool.block_table ? scalar_load_int(a.pool.block_table + bu * a.pool.max_blocks) : bu * a.pool.max_blocks;
     const elem_t* kp = pool + (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() +
                        (size_t)page * a.pool.page_elems() + c * EPL;
     const size_t v_off = a.pool.kv_elems();
@@ -356,10 +391,6 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     // 2*NT loads are in flight together; tiles past S are masked out of the arithmetic instead
     raw_t kb[NT], vb[NT];
     float bs[NT];
-    // an all-ones description mask (every equal-length batch) leaves the bias all zero: build_bias_kernel says so in a device
-    // word, read through the scalar cache; the uniform branch below then drops the NT mask loads of every lane
-    const bool has_bias = a.bias != nullptr && (a.bias_flag == nullptr || scalar_load_int(a.bias_flag) != 0);
-    const float* brow = a.bias + (size_t)bu * a.ld_bias;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         int tok = u * TPW + tt;
@@ -372,15 +403,10 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
         tok = tok < S ? tok : S - 1;
         vb[u] = *reinterpret_cast<const raw_t*>(kp + v_off + (size_t)tok * PTTS_HEAD_DIM);
     }
-    float q[EPL];
-    {
-        const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL);
-#pragma unroll
-        for (int j = 0; j < EPL / 4; ++j) {
-            const f32x4 v = qp[j];
-            q[4 * j] = v[0]; q[4 * j + 1] = v[1]; q[4 * j + 2] = v[2]; q[4 * j + 3] = v[3];
-        }
-    }
+    // an all-ones description mask (every equal-length batch) leaves the bias all zero: build_bias_kernel says so in a device
+    // word, read through the scalar cache; the uniform branch below then drops the NT mask loads of every lane
+    const bool has_bias = a.bias != nullptr && (a.bias_flag == nullptr || scalar_load_int(a.bias_flag) != 0);
+    const float* brow = a.bias + (size_t)bu * a.ld_bias;
 #pragma unroll
     for (int u = 0; u < NT; ++u) bs[u] = 0.f;
     if (has_bias) {
@@ -389,23 +415,6 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
             int tok = u * TPW + tt;
             tok = tok < S ? tok : S - 1;
             bs[u] = brow[tok];
-        }
-    }
-    // look-ahead query: statistics partials of row b (one 16-column block per lane) and this lane's c1 / c2 slice
-    const bool lnfix = a.lnfix_stat != nullptr;
-    float st_s = 0.f, st_q = 0.f, fc1[EPL], fc2[EPL];
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) { fc1[j] = 0.f; fc2[j] = 0.f; }
-    if (lnfix) {
-        const float* sp = a.lnfix_stat + ((size_t)(b >> 5) * a.lnfix_blocks * 32 + (b & 31)) * 2;
-        for (int nbk = lane; nbk < a.lnfix_blocks; nbk += 64) {
-            st_s += sp[(size_t)nbk * 64];
-            st_q += sp[(size_t)nbk * 64 + 1];
-        }
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            fc1[j] = a.lnfix_c1[h * PTTS_HEAD_DIM + c * EPL + j];
-            fc2[j] = a.lnfix_c2[h * PTTS_HEAD_DIM + c * EPL + j];
         }
     }
 #ifdef PTTS_STAMPS
@@ -419,6 +428,15 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(vb[u]));
     if (lnfix) {
+        float st_s = (lane < nblk ? p0.x : 0.f) + (lane + 64 < nblk ? p1.x : 0.f);
+        float st_q = (lane < nblk ? p0.y : 0.f) + (lane + 64 < nblk ? p1.y : 0.f);
+        for (int nbk = lane + 128; nbk < nblk; nbk += 64) {        // rows wider than 2048 features
+            st_s += sp[(size_t)nbk * 64];
+            st_q += sp[(size_t)nbk * 64 + 1];
+        }
+        float fc1[EPL], fc2[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { fc1[j] = c1r[j >> 2][j & 3]; fc2[j] = c2r[j >> 2][j & 3]; }
         const float K = (float)(a.lnfix_blocks * 16);
         const float mean = a.lnfix_rms ? 0.f : wave_sum(st_s) / K;
         const float var = a.lnfix_rms ? wave_sum(st_q) / K : fmaxf(wave_sum(st_q) / K - mean * mean, 0.f);
