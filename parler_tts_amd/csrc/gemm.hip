@@ -194,8 +194,16 @@ __device__ inline void epilogue(const GemmArgs& a, int epi, int row, int n, f32x
     }
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD, int EPI_T = -1, int ACT_T = -1, int W2_T = -1, int TILES_T = 0>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD, int EPI_T = -1, int ACT_T = -1, int W2_T = -1, int TILES_T = 0,
+          bool QR = false>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
+    // QR (H2 = 1, no fold, no second role): one 8-ROW QUARTER of the m-tile per workgroup instead of a 16-row half.  The
+    // residual projections with N = 1024 have 64 feature blocks: 128 half-workgroups leave half of the 256 CUs idle while each
+    // busy CU pulls 256 KB (fc2) through its 64 B / clock load path - the stamps' longest phase.  Quarters put 256 workgroups
+    // on the chip (192 KB each for fc2).  The MFMA still multiplies 16 activation columns: lanes 8 .. 15 of each 16-lane group
+    // load the rows of lanes 0 .. 7 again, their (duplicate) results are dropped - every kept element is the same dot product
+    // in the same order as on the half-split grid (bit-identical).
+    static_assert(!QR || (H2 == 1 && !FOLD && !STAGE && W2_T == 0 && NB == 1), "quarter-row workgroups: plain residual projections only");
     // EPI_T / ACT_T: see epilogue().  W2_T = 0: the launch has no second role (the look-ahead code is compiled out).
     // TILES_T > 0 (fragment input): K / KSTEP == NW * TILES_T exactly - every wave streams TILES_T tiles in ONE burst with no
     // per-tile guard, so the tile addresses are a compile-time stride apart (the guarded form recomputes each address with a
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // With a VGPR-derived index the compiler implements the guards by EXEC masking and drops the skip-branch
     // over short blocks - but MFMA ignores EXEC, so an empty tile slot would accumulate unloaded registers.
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int nb0 = blockIdx.x * NB, hsel = 0;
+    int nb0 = blockIdx.x * NB, hsel = 0, rsel = 0;
     bool role2 = false;
     if (H2 == 1) {
         int id = blockIdx.x;
@@ -248,8 +256,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             a.epi = EPI_ROWMAJOR; a.out = a.out2; a.ldo = a.ldo2;
             a.bias = nullptr; a.rowmask = nullptr; a.act = ACT_NONE; a.xfrag_out = nullptr; a.xstat = nullptr;
         }
-        nb0 = (((id >> 4) << 3) + (id & 7)) * NB;
-        hsel = (id >> 3) & 1;
+        if (QR) {      // groups of 8 blocks x 4 quarters; the quarters of a block sit 8 apart (same XCD: its L2 serves the re-reads)
+            nb0 = ((id >> 5) << 3) + (id & 7);
+            hsel = (id >> 4) & 1;
+            rsel = (id >> 3) & 1;
+        } else {
+            nb0 = (((id >> 4) << 3) + (id & 7)) * NB;
+            hsel = (id >> 3) & 1;
+        }
         if (nb0 * 16 >= a.N) return;            // padding blocks of the last group of 8 (no stamp record: zeros)
     } else if (W2_T != 0 && !STAGE && !FOLD && a.W2) {       // wide second role: 32-row workgroups, the look-ahead blocks follow the first role's
         const int ids1 = a.N / (16 * NB);
@@ -285,8 +299,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     bool have_res = false;
     if (epi == EPI_RESIDUAL && tid < NB * 64 * H2) {
         const int ln = tid & 63, hh = H2 == 2 ? ((tid >> 6) & 1) : hsel, ii = H2 == 2 ? (tid >> 7) : (tid >> 6);
-        const int row = m0 + 16 * hh + (ln & 15), n = (nb0 + ii) * 16 + 4 * (ln >> 4);
-        if (row < a.M && n < a.N) { xres = *reinterpret_cast<const float4*>(a.out + (size_t)row * a.ldo + n); have_res = true; }
+        const int row = m0 + 16 * hh + (QR ? 8 * rsel + (ln & 7) : (ln & 15)), n = (nb0 + ii) * 16 + 4 * (ln >> 4);
+        if (row < a.M && n < a.N && (!QR || (ln & 8) == 0)) {
+            xres = *reinterpret_cast<const float4*>(a.out + (size_t)row * a.ldo + n);
+            have_res = true;
+        }
     }
     float4 c1v = make_float4(0, 0, 0, 0), c2v = make_float4(0, 0, 0, 0);
     if (FOLD && tid < 64 * H2) {
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                     const int kk = role2 && !lo ? ks - a.ksplit : ks;
                     const int ksrc = !role2 ? K : (lo ? a.ksplit * KSTEP : K - a.ksplit * KSTEP);
                     const elem_t* xf = reinterpret_cast<const elem_t*>(lo ? a.xfrag_lo : a.xfrag) + (size_t)blockIdx.y * 32 * ksrc +
-                                       (size_t)(kk * 2 + hsel) * TILE + lane * EPL;
+                                       (size_t)(kk * 2 + hsel) * TILE + (QR ? ((lane & 0x30) | (8 * rsel + (lane & 7))) : lane) * EPL;
                     bt[STAGE ? 0 : u][0] = T::load_global(xf);
                     if (H2 == 2) bt[STAGE ? 0 : u][STAGE ? 0 : H2 - 1] = T::load_global(xf + TILE);
                 }
@@ -513,7 +530,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             s += p;
             if (gated) s1 += redv[((ww * NB + 1) * 2 + h) * 64 + ln];
         }
-        const int row = m0 + 16 * (H2 == 2 ? h : hsel) + (ln & 15);
+        const int row = m0 + 16 * (H2 == 2 ? h : hsel) + (QR ? 8 * rsel + (ln & 7) : (ln & 15));
+        const bool lane_ok = !QR || (ln & 8) == 0;          // quarter rows: lanes 8 .. 15 of a group hold duplicates
         if (FOLD) {
             float sx = 0.f, sq = 0.f;
             for (int ww = 0; ww < NW; ++ww) {
@@ -530,7 +548,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             s[3] = rstd * (s[3] - mean * c1v.w) + c2v.w;
         }
         const int n = gated ? blockIdx.x * 16 + 4 * (ln >> 4) : (nb0 + i) * 16 + 4 * (ln >> 4);
-        if (row < a.M) {
+        if (row < a.M && lane_ok) {
             if (EPI_T >= 0 && role2) epilogue<P, EPI_ROWMAJOR, ACT_NONE>(a, EPI_ROWMAJOR, row, n, s, s1, xres, false);
             else epilogue<P, EPI_T, ACT_T>(a, epi, row, n, s, s1, xres, have_res && t == tid);
         }
@@ -549,8 +567,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             }
             ps += __shfl_xor(ps, 16); pq += __shfl_xor(pq, 16);
             ps += __shfl_xor(ps, 32); pq += __shfl_xor(pq, 32);
-            if (ln < 16 && row < a.M) {
-                float* st2 = a.xstat + (((size_t)blockIdx.y * (a.N / 16) + nb0 + i) * 32 + 16 * (H2 == 2 ? h : hsel) + ln) * 2;
+            if (ln < (QR ? 8 : 16) && row < a.M) {
+                float* st2 = a.xstat + (((size_t)blockIdx.y * (a.N / 16) + nb0 + i) * 32 + 16 * (H2 == 2 ? h : hsel) + 8 * rsel + ln) * 2;
                 st2[0] = ps;
                 st2[1] = pq;
             }
@@ -563,7 +581,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #endif
 }
 
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false, int EPI_T = -1, int ACT_T = -1, int W2_T = -1, int TILES_T = 0>
+template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false, int EPI_T = -1, int ACT_T = -1, int W2_T = -1, int TILES_T = 0,
+          bool QR = false>
 hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int KC = 256 * KI;
     constexpr int PAD = 16 / (int)sizeof(typename P::elem_t);
@@ -572,10 +591,10 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t stream) {
     const size_t red_bytes = (size_t)NW * NB * 2 * 64 * 16 + (FOLD ? (size_t)NW * 2 * 2 * 16 * 4 : 0);
     if (lds < red_bytes) lds = red_bytes;
     dim3 grid((a.N + 16 * NB - 1) / (16 * NB), (a.M + 31) / 32);
-    if (H2 == 1) grid.x = ((grid.x + 7) / 8) * 16;     // groups of 8 blocks x 2 halves
+    if (H2 == 1) grid.x = ((grid.x + 7) / 8) * (QR ? 32 : 16);     // groups of 8 blocks x 2 halves (x 4 quarters)
     if (H2 == 1 && !STAGE && !FOLD && a.W2) grid.x += ((a.N2 / 16 + 7) / 8) * 16;   // + the look-ahead role
     if (H2 == 2 && !STAGE && !FOLD && a.W2) grid.x += a.N2 / (16 * NB);              // + the look-ahead role, 32-row workgroups
-    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD, EPI_T, ACT_T, W2_T, TILES_T>;
+    auto kern = gemm_kernel<P, NW, NB, STAGE, KI, H2, FOLD, EPI_T, ACT_T, W2_T, TILES_T, QR>;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -604,7 +623,7 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     // (with a second role the half-split grid is used for every M: the arithmetic must not depend on the batch size)
     const bool halves = a.N <= 2048 && (a.M > 16 || a.W2) && a.epi != EPI_GATED_FRAG && !(a.W2 && a.wide2);
     // ---- the decode step's projections on instances with a compile-time epilogue (PTTS_GEMM_GENERIC=1: the generic ones, A/B) ----
-    static const bool generic_only = getenv("PTTS_GEMM_GENERIC") != nullptr;
+    const bool generic_only = getenv("PTTS_GEMM_GENERIC") != nullptr;
     if (!generic_only && !a.force_whole && !a.bias && !a.rowmask) {
         const int tiles = (ksteps % nw == 0) ? ksteps / nw : 0;      // exact fit: one unguarded burst of `tiles` tiles per wave
         if (a.fold && !a.W2 && nw == 8 && !(halves)) {          // folded, 32-row workgroups, K <= 2048 (bf16) / 1024 (fp32)
@@ -622,6 +641,12 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
         if (!a.fold && halves && a.epi == EPI_RESIDUAL) {        // residual projections on the half-split grid
             // (the second role of the look-ahead launch streams 2 K: its workgroups need two bursts, so no exact-fit form)
             if (a.W2 && nw == 8) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, -1>(a, stream);
+            // quarter-row workgroups where the half-split grid would leave CUs idle (<= 128 half-workgroups) and the rows exist
+            const bool no_quarters = getenv("PTTS_GEMM_NO_QUARTERS") != nullptr;      // A/B and the equivalence test
+            const bool quarters = !no_quarters && !a.W2 && a.M > 16 && a.N <= 1024 && (a.M + 31) / 32 == 1;
+            if (quarters && nw == 8 && tiles == 4) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0, 4, true>(a, stream);
+            if (quarters && nw == 8 && tiles == 8) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0, 8, true>(a, stream);
+            if (quarters && nw == 16 && tiles == 8) return launch_one<P, 16, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0, 8, true>(a, stream);
             if (!a.W2 && nw == 8) {
                 if (tiles == 4) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0, 4>(a, stream);
                 if (tiles == 8) return launch_one<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, 0, 8>(a, stream);

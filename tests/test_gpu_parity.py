@@ -1668,6 +1668,30 @@ def test_folded_and_staged_layernorm_agree(hip):
     assert (a.argmax(-1) == b.argmax(-1)).float().mean().item() > 0.9
 
 
+def test_specialised_gemm_instances_equal_the_generic_ones_bit_for_bit(hip):
+    """The decode projections run on GEMM instances with a compile-time epilogue, one unguarded tile burst per wave and (N = 1024
+    residual projections, one m-tile) 8-row quarter workgroups.  Same products, same order: at mini_v0.1 widths, batch 32 and
+    batch 19 (a quarter with three rows, an empty one), bf16 and fp32, the teacher-forced logits must be BIT-IDENTICAL to
+    the generic instances (PTTS_GEMM_GENERIC=1) and to the half-split grid (PTTS_GEMM_NO_QUARTERS=1)."""
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    cfg.decoder.num_hidden_layers = 2
+    sd = synthetic_state_dict(cfg, seed=7, never_eos=True, ln_jitter=0.1, parts=("decoder",))
+    for dtype in ("bf16", "fp32"):
+        for B in (32, 19):
+            got, want, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=B, T=40, P=16, L=8, seed=8, steps=6)
+            assert (got - want).abs().max() < (0.1 if dtype == "bf16" else 5e-4)
+            for var in ("PTTS_GEMM_NO_QUARTERS", "PTTS_GEMM_GENERIC"):
+                os.environ[var] = "1"
+                try:
+                    alt, _, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=B, T=40, P=16, L=8, seed=8, steps=6, reuse_ref=True)
+                finally:
+                    del os.environ[var]
+                assert torch.equal(got, alt), (dtype, B, var, float((got - alt).abs().max()))
+
+
 def test_page_attention_kernel_equals_general_kernel(hip):
     """cross-attention over a single page: one-wave kernel vs the general paged kernel (same arithmetic, other order)"""
     for name in ("tiny_greedy_ragged", "tiny_cfg"):      # padded description keys / fully masked null rows
