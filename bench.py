@@ -364,6 +364,25 @@ def main():
                 "sampled_step_ms_eager": round(prof.step_ms / max(prof.steps, 1), 3),
             },
         }
+        # the weakest part of the step on the record next to the strongest: everything but the self-attention launches
+        # (6 projection / cross-attention launches per layer + heads, embed, select, advance) streams the decoder weights and
+        # the cross K/V once per step; its time = the loop's per-step time minus layers x the self-attention launch average
+        if phase["decode_ms"] and prof.launches:
+            dec = cfg.decoder
+            esz = 2 if args.dtype == "bf16" else 4
+            D_, L_, F_ = dec.hidden_size, dec.num_hidden_layers, dec.ffn_dim
+            chain_bytes = (L_ * (6 * D_ * D_ + 2 * D_ * F_ + 6 * D_) + 2 * D_ + dec.num_codebooks * dec.vocab_size * D_) * esz \
+                + L_ * 2 * B * T * D_ * esz
+            step_ms = phase["decode_ms"] / args.steps / n_steps
+            chain_ms = step_ms - L_ * (prof.total_ms / prof.launches)
+            gbs = chain_bytes / 1e9 / max(chain_ms / 1e3, 1e-9)
+            line["roofline_projection_chain"] = {
+                "kernel": "gemm_kernel / attn_page_kernel / select / embed launches of a decode step (all but the self-attention launches)",
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_step": int(chain_bytes), "ms_per_step": round(chain_ms, 4),
+                "launches_per_step": 6 * L_ + 4,
+                "derived": "decode loop ms per step (graph replay) minus layers x the sampled self-attention launch average",
+                "counters": "profiles/r03_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
         if dp is not None:
             line["data_parallel"] = dp
         line["profile_every"] = args.profile_every    # every n-th decode step of the timed region runs eagerly with events
