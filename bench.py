@@ -63,7 +63,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg, sd, B, T, P, L, budget_s=25.0, full_b1=False):
+def cpu_baseline(cfg, sd, B, T, P, L, budget_s=34.0, full_b1=False):
     """Bounded sample of the CPU port on the same workload: decode steps at the start of the run
     (S ~ P) and in the middle (S ~ P + L/2), integrated over the whole run with the linear-in-S cost model.  Three legs:
     the reference-shaped cat-grown KV cache at batch B (`value`: what the reference's own code does, M:303-304), a static

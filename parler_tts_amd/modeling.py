@@ -456,6 +456,9 @@ class ParlerTTSForConditionalGeneration:
     def generate(self, inputs: Optional[torch.Tensor] = None, generation_config: Optional[GenerationConfig] = None,
                  logits_processor=None, stopping_criteria=None, synced_gpus: Optional[bool] = None, streamer=None,
                  **kwargs):
+        # `synced_gpus` (M:2349, handed to the third-party loop at M:2590): under ZeRO-3 it keeps every rank stepping until all
+        # have finished, because the WEIGHTS are sharded; here every rank holds all weights (distributed.py), a rank's extra
+        # steps could only produce pad tokens, so the flag is accepted and changes nothing.
         # every stream handle, lazy allocation and launch below follows the CURRENT device: make it the model's
         with torch.cuda.device(self.device):
             return self._generate(inputs, generation_config, logits_processor, stopping_criteria, synced_gpus, streamer,
