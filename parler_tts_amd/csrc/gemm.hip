@@ -353,6 +353,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // only for what it needs while the weights are still in flight.
     const int cend0 = cstep < ksteps ? cstep : ksteps;
     if (!STAGE) load_burst(w, cend0);
+    // (Pulling the epilogue's kernel-argument lines and state->pos into SGPRs here, under the tile burst, was measured too:
+    // decode pass 3617 -> 3630 ms.  Like the batch at kernel entry it loses; hipcc's own placement stays.)
 #ifdef PTTS_STAMPS
     stv[2] = stamp_cycles();
     if (!STAGE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stv[3] = stamp_cycles(); }
