@@ -312,6 +312,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         c2v = *reinterpret_cast<const float4*>(a.c2 + n);
     }
     float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};
+    // bf16 folded path: the row statistics come from the matrix cores - ones . x (every output row = the column sums) and
+    // x . x^T (its diagonal = the sums of squares), two MFMAs per fragment instead of ~100 cycles of VALU unpack / add / fma
+    // per fragment (round-3 stamps: the folded instances' MFMA phase was 860-1000 cycles against 200-350 on the plain ones).
+    // The activation fragment serves as BOTH operands of the second product: A- and B-fragment layouts hold element
+    // (row l & 15, k = 8 (l >> 4) + j) in the same lane and slot.  (Round 1's first statistics also came from MFMAs and were
+    // blamed for a rare wrong value; the cause was the inline-asm hand-over store behind the last MFMA, fixed in round 2.)
+    constexpr bool MSTAT = FOLD && P::IS_BF16;
+    f32x4 ms_sum[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, ms_sq[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    typename T::wfrag ones_frag;
+    if (MSTAT) {
+        const u32x4 o = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};       // eight bf16 1.0
+        ones_frag = __builtin_bit_cast(typename T::wfrag, o);
+    }
     const int cstep = STAGE ? KC / KSTEP : ksteps;   // only the LDS-staged path needs K chunks
 
     // first burst of this wave's weight tiles: issued before the prologue so HBM latency hides under it
@@ -482,7 +495,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                         T::mma(wt[u][i], b0, acc[i][0]);
                         if (H2 == 2) T::mma(wt[u][i], b1, acc[i][1]);
                     }
-                    if (FOLD) {
+                    if (MSTAT) {
+                        T::mma(ones_frag, b0, ms_sum[0]);
+                        T::mma(b0, b0, ms_sq[0]);
+                        if (H2 == 2) { T::mma(ones_frag, b1, ms_sum[1]); T::mma(b1, b1, ms_sq[1]); }
+                    } else if (FOLD) {
                         T::stats(b0, st_sum[0], st_sq[0]);
                         if (H2 == 2) T::stats(b1, st_sum[1], st_sq[1]);
                     }
@@ -509,6 +526,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     if (FOLD) {
 #pragma unroll
         for (int h = 0; h < H2; ++h) {
+            if (MSTAT) {
+                // ones . x: every accumulator row holds the column sums, lane l < 16 has activation row l in slot 0;
+                // x . x^T: element (i, i) sits in lane 16 (i >> 2) + i, slot i & 3
+                if (lane < 16) lds_store_b32(&stat[((w * 2 + h) * 2 + 0) * 16 + lane], ms_sum[h][0]);
+                if ((lane >> 4) == ((lane & 15) >> 2)) {
+                    const f32x4 q4 = ms_sq[h];
+                    const int m = lane & 3;
+                    lds_store_b32(&stat[((w * 2 + h) * 2 + 1) * 16 + (lane & 15)], m == 0 ? q4[0] : (m == 1 ? q4[1] : (m == 2 ? q4[2] : q4[3])));
+                }
+                continue;
+            }
             float sv = st_sum[h], qv = st_sq[h];
             sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
             sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
