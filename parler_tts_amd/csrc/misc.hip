@@ -25,11 +25,13 @@ template <> struct Vec4<PF32> {
 template <typename P>
 __global__ __launch_bounds__(256) void embed_codebooks_kernel(EmbedArgs a) {
     typedef typename P::elem_t elem_t;
-    __shared__ int toks[32];
     const int b = blockIdx.x;
-    const int pos = a.state->pos;
-    if ((int)threadIdx.x < a.K) toks[threadIdx.x] = a.tok_in[b * a.K + threadIdx.x];
-    __syncthreads();
+    // the step's position and this utterance's K token ids are uniform per workgroup: scalar-cache reads (no vector round trip,
+    // no LDS hand-over, no barrier in front of the row gathers)
+    const int pos = scalar_load_int(&a.state->pos);
+    int toks[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) toks[k] = k < a.K ? scalar_load_int(a.tok_in + b * a.K + k) : 0;
     const elem_t* tab = reinterpret_cast<const elem_t*>(a.tables);
     const elem_t* ptab = reinterpret_cast<const elem_t*>(a.pos_table) + (size_t)pos * a.D;
     // 4 features per thread (D % 4 == 0); the K row gathers are independent vector loads issued together,
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void embed_codebooks_kernel(EmbedArgs a) {
             if (k < a.K) { s[0] = s[0] + e[k][0]; s[1] = s[1] + e[k][1]; s[2] = s[2] + e[k][2]; s[3] = s[3] + e[k][3]; }
         for (int k = 16; k < a.K; ++k) {
             float t[4];
-            Vec4<P>::load(tab + ((size_t)k * a.rows + toks[k]) * a.D + d, t);
+            Vec4<P>::load(tab + ((size_t)k * a.rows + scalar_load_int(a.tok_in + b * a.K + k)) * a.D + d, t);
             s[0] = s[0] + t[0]; s[1] = s[1] + t[1]; s[2] = s[2] + t[2]; s[3] = s[3] + t[3];
         }
         const float o[4] = {s[0] + pe[0], s[1] + pe[1], s[2] + pe[2], s[3] + pe[3]};
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     __shared__ unsigned sel_prefix, sel_remaining;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int V = a.vocab;          // valid ids; rows are a.V (= padded stride) apart
-    const int cur = a.state->cur_len;
+    const int cur = scalar_load_int(&a.state->cur_len);      // scalar cache: the logits loads below do not queue behind it
     if (cur >= a.L) return;
     const float* lg = a.logits + (size_t)row * a.V;
     const float* ug = a.guidance > 1.0f ? a.logits + (size_t)(row + a.rows) * a.V : nullptr;
