@@ -54,7 +54,11 @@ template <> struct KVLoad<PF32> {
 };
 
 // SELF only names the instantiation (self- vs cross-attention launches show up separately in rocprof)
-template <typename P, typename OP, bool SELF>
+// SPEC = 1 (experiment, PTTS_ATTN_SPEC=1): identity page table and no look-ahead-QKV prologue fixed at compile time.  The
+// generic instance steps over those two blocks (page-id copy loops, the LayerNorm-finishing prologue) with taken branches;
+// round-3 prologue stamps read 3000 cycles between "first K burst issued" and "pass 1 starts" and the specialisation was
+// built to remove them - it measured slower than the generic instance (attn_decode_launch), so it is not the default.
+template <typename P, typename OP, bool SELF, int SPEC = 0>
 __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     typedef typename P::elem_t elem_t;
     typedef KVLoad<P> L;
@@ -81,12 +85,16 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
                  "s"(a.ldq), "s"(a.layer), "s"(a.len), "s"(a.len_from_state), "s"(a.pool.max_blocks), "s"(a.pool.H), "s"(a.pool.n_pages),
                  "s"(a.rows_per_utt), "s"(a.alive_k), "s"(a.alive_b), "s"(a.lnfix_qkv), "s"(a.s_cap), "s"(a.D));
 #endif
+#ifdef PTTS_STAMPS_ATTN_PROLOGUE
+    stv[2] = stamp_cycles();       // kernel arguments in SGPRs
+#endif
     const int h = blockIdx.x, b = blockIdx.y;                    // b: query row; bu: the utterance whose cache it reads
     const int bu = b / a.rows_per_utt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tt = lane / LPT, c = lane % LPT;                    // token-in-tile, 16-byte chunk of the row
     const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
-    const bool ident = a.pool.block_table == nullptr;      // identity table: page of block i is bu * max_blocks + i
+    const bool ident = SPEC == 1 ? true : a.pool.block_table == nullptr;      // identity table: page of block i is bu * max_blocks + i
+    const bool lnq = SPEC == 1 ? false : a.lnfix_qkv != 0;                    // look-ahead QKV prologue
     const int page0 = bu * a.pool.max_blocks;
     const size_t page_elems = a.pool.page_elems();       // stride between two pages inside this head's K (or V) slab
     const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
@@ -105,17 +113,20 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         for (int k = 0; k < 16; ++k) uflag[k] = scalar_load_int(u + k);
     }
     float q[EPL];
-    if (!a.lnfix_qkv) {
+    if (!lnq) {
         const float* qp = a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) q[j] = qp[j];
     }
+#ifdef PTTS_STAMPS_ATTN_PROLOGUE
+    stv[3] = stamp_cycles();       // state / flags / q requested (the stamp's own wait covers the scalar ones)
+#endif
     // Early K burst: under the identity page table the addresses of the wave's first UNR key tiles depend on nothing but
     // kernel arguments, so they go out BEFORE the context length is known (state->pos and the finished-utterance flags are
     // dependent trips to memory: 1.5 us from kernel entry to the first K load in the round-3 stamps).  Token indices are
     // clamped to the utterance's page run (capacity) instead of S - 1; rows at or past S may hold anything - their scores
     // are never written (score_burst tests tok < S) and no V tile is requested before S is known.
-    const bool early = ident && !a.lnfix_qkv;
+    const bool early = ident && !lnq;
     raw_t bufA[UNR], bufB[UNR];
     if (early) {
         const int cap = a.pool.max_blocks * PTTS_PAGE_TOKENS - 1;
@@ -128,6 +139,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
             bufA[u] = __builtin_nontemporal_load(src);
         }
     }
+#ifdef PTTS_STAMPS_ATTN_PROLOGUE
+    stv[4] = stamp_cycles();       // q, state, flags requested; early K burst issued (the stamp waits for the scalar loads)
+#endif
     int S = a.len_from_state ? (pos_ld + 1) : a.len;
     const int pos_append = S - 1;                                 // cache position of this step's own k / v (append-only cache)
     if (a.unfinished) {                                           // finished utterance: one key instead of the whole cache
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     // page ids once into LDS: KV addresses then depend on no global load
     if (!ident)
         for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[bu * a.pool.max_blocks + i];
-    if (a.lnfix_qkv) {
+    if (lnq) {
         // Look-ahead QKV: `a.q` is the raw product x.Wqkv'^T this head's slices of which still need the LayerNorm of the
         // folded projection, rstd * (raw - mean * c1) + c2, from the per-block statistics the producing launch wrote.
         // Waves 0..2 take q, k, v (64 values each): q goes to LDS (scaled), k and v are appended to the cache at
@@ -209,7 +223,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         int t0 = w;
         if (!early) load_burst(bufA, t0, 0);
 #ifdef PTTS_STAMPS
+#ifdef PTTS_STAMPS_ATTN_PROLOGUE
+        stv[5] = stamp_cycles();   // pass 1 starts
+#else
         stv[2] = stamp_cycles();
+#endif
 #endif
         while (true) {
             bool more = t0 + STRIDE < ntiles;
@@ -228,7 +246,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     load_burst(bufA, w, v_off);
     __syncthreads();
 #ifdef PTTS_STAMPS
+#ifdef PTTS_STAMPS_ATTN_PROLOGUE
+    stv[6] = stamp_cycles();       // scores done
+#else
     stv[3] = stamp_cycles();
+#endif
 #endif
 
     // ---------------- softmax over [0, S) ----------------
@@ -255,7 +277,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     for (int i = 0; i < NWAVES; ++i) sum += wred[i];
     for (int t = tid; t < S; t += NWAVES * 64) sc[t] = sc[t] / sum;
     __syncthreads();
-#ifdef PTTS_STAMPS
+#if defined(PTTS_STAMPS) && !defined(PTTS_STAMPS_ATTN_PROLOGUE)
     stv[4] = stamp_cycles();
 #endif
 
@@ -300,7 +322,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) red[w * 64 + c * EPL + j] = acc[j];
     }
-#ifdef PTTS_STAMPS
+#if defined(PTTS_STAMPS) && !defined(PTTS_STAMPS_ATTN_PROLOGUE)
     stv[5] = stamp_cycles();
 #endif
     __syncthreads();
@@ -312,7 +334,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         of[frag_off<OP>(b & 31, h * PTTS_HEAD_DIM + tid)] = to_elem<OP>(o);
     }
 #ifdef PTTS_STAMPS
+#ifndef PTTS_STAMPS_ATTN_PROLOGUE
     stv[6] = stamp_cycles();
+#endif
     stv[7] = stamp_realtime();
     stamp_store(stref, stv);
 #endif
@@ -705,10 +729,16 @@ hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, 
     }
     size_t lds = ((size_t)a.s_cap + NWAVES * 64 + NWAVES + a.pool.max_blocks + 64) * sizeof(float);   // + 64: look-ahead q
     dim3 grid(H, B), block(NWAVES * 64);
+    // the compile-time specialised instance is an experiment switch (PTTS_ATTN_SPEC=1): smaller code, no taken branches over
+    // the unused blocks - and measured SLOWER (decode pass 3586 -> 3609 ms, 29.0 -> 29.3 us per launch), so the generic one stays
+    const bool spec = a.pool.block_table == nullptr && !a.lnfix_qkv && getenv("PTTS_ATTN_SPEC") != nullptr;
 #define PTTS_ATTN_LAUNCH(P_, O_)                                                                             \
     do {                                                                                                     \
         /* profiled launches: events bound to THIS dispatch (its own start / end timestamps, no barrier packets) */ \
-        if (ev_start && a.len_from_state)                                                                    \
+        if (spec && ev_start && a.len_from_state)                                                            \
+            hipExtLaunchKernelGGL((attn_decode_kernel<P_, O_, true, 1>), grid, block, (uint32_t)lds, stream, ev_start, ev_stop, 0, a); \
+        else if (spec && a.len_from_state) hipLaunchKernelGGL((attn_decode_kernel<P_, O_, true, 1>), grid, block, lds, stream, a); \
+        else if (ev_start && a.len_from_state)                                                               \
             hipExtLaunchKernelGGL((attn_decode_kernel<P_, O_, true>), grid, block, (uint32_t)lds, stream, ev_start, ev_stop, 0, a); \
         else if (ev_start)                                                                                   \
             hipExtLaunchKernelGGL((attn_decode_kernel<P_, O_, false>), grid, block, (uint32_t)lds, stream, ev_start, ev_stop, 0, a); \
