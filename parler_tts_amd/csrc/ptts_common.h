@@ -119,6 +119,8 @@ struct StepState {
 // compiles to a global_load + s_waitcnt vmcnt(0) in front of everything queued behind it.
 typedef const int __attribute__((address_space(4))) ptts_cint;
 __device__ inline int scalar_load_int(const int* p) { return *reinterpret_cast<ptts_cint*>(reinterpret_cast<uintptr_t>(p)); }
+typedef const float __attribute__((address_space(4))) ptts_cfloat;
+__device__ inline float scalar_load_float(const float* p) { return *reinterpret_cast<ptts_cfloat*>(reinterpret_cast<uintptr_t>(p)); }
 
 // ---- K-split hand-over stores --------------------------------------------------------------------------------
 // MFMA accumulators go to LDS through PLAIN C++ stores, never through an `asm` statement: hipcc pads the gfx950
