@@ -183,3 +183,14 @@ def test_generation_config_refuses_fields_it_does_not_serve():
                 dict(some_future_knob=1)):
         with pytest.raises(NotImplementedError):
             GenerationConfig(**bad).validate()
+
+
+def test_dac_kernel_counts_hook_answers_without_a_gpu(built_lib):
+    """ptts_dac_kernel_counts (ABI v7) is host-side bookkeeping: it must answer (all zero) in a process that never touched a GPU"""
+    from parler_tts_amd import _hip
+
+    counts = _hip.dac_kernel_counts(reset=True)
+    assert list(counts) == _hip.DAC_KERNEL_KINDS and len(counts) == 14 and set(counts.values()) == {0}
+    import ctypes as C
+
+    assert _hip.load_library().ptts_dac_kernel_counts(None, 0, 0) == -1
