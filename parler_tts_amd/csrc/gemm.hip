@@ -187,8 +187,15 @@ __device__ inline void epilogue(const GemmArgs& a, int epi, int row, int n, f32x
             } else { b = row / a.T; tok = row - b * a.T; }
             elem_t* c = reinterpret_cast<elem_t*>(a.pool.base) +
                         a.pool.elem_off(b, a.layer, kv, nn >> 6, tok) + (nn & 63);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] = to_elem<P>(v[r]);
+            // the lane's four consecutive features are contiguous in the cache row: ONE 8-byte (bf16) / 16-byte (fp32) store
+            if (P::IS_BF16) {
+                uint2 pk;
+                pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{v[0], v[1]}, bf16x2));
+                pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{v[2], v[3]}, bf16x2));
+                *reinterpret_cast<uint2*>(c) = pk;
+            } else {
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            }
             break;
         }
     }
