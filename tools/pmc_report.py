@@ -24,9 +24,17 @@ if mode == "decoder":
             ("gemm_kernel<PBF16, 16, 1, false, 1, 1, false>", 128): "fc2 + residual                        8.39 MB",
             ("gemm_kernel<PBF16, 8, 1, false, 1, 2, true>", 612): "final LN + 9 LM heads (folded)      20.05 MB",
             ("attn_decode_kernel<PBF16, PBF16, true>", 512): "self-attention, S ~ 1266            165.9 MB",
-            ("attn_page_kernel<PBF16, PBF16>", 128): "cross-attention, T = 40               5.24 MB"}
-    print("kernel (workgroups x threads)                      launch = algorithmic weight/KV bytes      | fabric rd MB  wr MB | L2 hit % | "
-          "L1->L2 read latency (cycles) | wave cycles: issuing % / parked on s_waitcnt+barrier % / issue-stalled % | MFMA busy % of SQ busy")
+            ("attn_page_kernel<PBF16, PBF16>", 128): "cross-attention, T = 40               5.24 MB",
+            # the final build of round 3: instances with a compile-time epilogue / exact-fit bursts / quarter-row workgroups
+            ("gemm_kernel<PBF16, 8, 1, false, 1, 2, true, 3, 0, 0, 4, false>", 192): "LN1 + QKV projection (folded)        6.29 MB",
+            ("gemm_kernel<PBF16, 8, 1, false, 1, 1, false, 1, 0, -1, 0, false>", 256): "self out-proj + look-ahead cross-q   6.29 MB",
+            ("gemm_kernel<PBF16, 8, 1, false, 1, 1, false, 1, 0, 0, 4, true>", 256): "cross out-proj (quarter rows)         2.10 MB",
+            ("gemm_kernel<PBF16, 8, 1, false, 1, 2, true, 2, 1, 0, 4, false>", 256): "LN3 + fc1 + GELU (folded)            8.39 MB",
+            ("gemm_kernel<PBF16, 16, 1, false, 1, 1, false, 1, 0, 0, 8, true>", 256): "fc2 + residual (quarter rows)         8.39 MB",
+            ("gemm_kernel<PBF16, 8, 1, false, 1, 2, true, 0, 0, 0, 4, false>", 612): "final LN + 9 LM heads (folded)      20.05 MB",
+            ("attn_decode_kernel<PBF16, PBF16, true, 0>", 512): "self-attention, S ~ 1266            165.9 MB"}
+    print("kernel (workgroups x threads)                                          launch = algorithmic weight/KV bytes      | fabric rd MB  wr MB | L2 hit % | "
+          "L1->L2 read latency (cycles) | wave cycles: issuing % / parked on s_waitcnt+barrier % / issue-stalled % | MFMA busy cycles (summed over the SIMDs) per 100 SQ busy cycles")
     for k, r in sorted(t1.items(), key=lambda x: -x[1]["mean_ns"] * x[1]["launches"]):
         c, c2, c3, cp, cs = (t[k]["per_launch"] for t in (t1, t2, t3, tp, sq))
         n32, n64, n128, tot = (c["TCC_EA0_RDREQ_%s" % x] for x in ("32B_sum", "64B_sum", "128B_sum", "sum"))
@@ -36,7 +44,7 @@ if mode == "decoder":
         lat = cp["TCP_TCC_READ_REQ_LATENCY_sum"] / max(cp["TCP_TCC_READ_REQ_sum"], 1)
         wc = cs["SQ_WAVE_CYCLES"]
         name = k[0].split("(")[0]
-        print(f"{name[:46]:46s} {k[1]:4d} x {k[2]:4d}  {role.get((name, k[1]), ''):44s} | {rd:8.2f} {wr:7.3f} | {100 * hit:6.1f}   | {lat:8.0f}"
+        print(f"{name[:66]:66s} {k[1]:4d} x {k[2]:4d}  {role.get((name, k[1]), ''):44s} | {rd:8.2f} {wr:7.3f} | {100 * hit:6.1f}   | {lat:8.0f}"
               f"                     | {100 * cs['SQ_ACTIVE_INST_ANY'] / wc:5.1f} / {100 * cs['SQ_WAIT_ANY'] / wc:5.1f} / {100 * cs['SQ_WAIT_INST_ANY'] / wc:5.1f}"
               f"                        | {100 * cs['SQ_VALU_MFMA_BUSY_CYCLES'] / max(cs['SQ_BUSY_CYCLES'], 1):5.1f}   (other RDREQ {tot - n32 - n64 - n128:.0f})")
 else:
