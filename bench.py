@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the generate() hot path: codec tokens/s + real-time factor, parler_tts_mini_v0.1, greedy, batch 32.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (one rank per GPU; the
+ranks read RANK / LOCAL_RANK / WORLD_SIZE), or plainly as ``python bench.py --gpus N``: the process then starts that very
+launcher as a CHILD before anything has touched a GPU, relays its output and ends with rank 0's JSON line and the child's
+return code.  ``--gpus N`` with fewer than N devices visible is an error (exit 2), never a silent one-GPU measurement.
 
 One "step" = one full ``ParlerTTSForConditionalGeneration.generate()`` pass over one batch of synthetic
 (description, prompt) pairs per GPU: T5 encoder -> prefill -> (max_length-1) decode steps -> un-delay ->
@@ -74,7 +79,7 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=34.0, full_b1=False):
     dec = cfg.decoder
     K, D, H = dec.num_codebooks, dec.hidden_size, dec.num_attention_heads
 
-    def timed_steps(Bx, S0, n, mode):
+    def timed_steps(Bx, S0, n, mode, raw=False):
         # KV cache of S0 positions filled with noise (values do not change the cost) and pre-projected cross K/V (M:287-294)
         enc_h = torch.randn(Bx, T, D) * 0.1
         amask = torch.ones(Bx, T, dtype=torch.long)
@@ -96,7 +101,7 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=34.0, full_b1=False):
             t0 = time.perf_counter()
             cpu_ref.decoder_forward(cfg, sd, ids, enc_h, amask, None, None, cache)
             ts.append(time.perf_counter() - t0)
-        return sum(ts) / len(ts), cache.length
+        return (ts if raw else sum(ts) / len(ts)), cache.length
 
     # pick the thread count that serves the CPU best on this box (oversubscription hurts small GEMMs)
     best = None
@@ -139,13 +144,34 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=34.0, full_b1=False):
         desc = ", ".join(f"S~{int(a)}: {b * 1e3:.0f} ms/step" for a, b in pts) + f"; degree-{deg} fit, max residual {resid * 100:.1f} %"
         return Bx * K * steps / total, desc, resid
 
+    def leg_b1(n=8):
+        """batch 1: a step is ~60 ms of small GEMVs whose time depends on which cores the threads land on more
+        than on S, so no polynomial is fitted: the MEDIAN of n steps at each of four cache lengths, piecewise-linear between them,
+        integrated over the run; the spread (max - min of a point's n steps over its median) is reported instead of a residual"""
+        import numpy as np
+
+        pts, spread = [], 0.0
+        for S0 in (P + 1, P + L // 4, P + L // 2, P + 3 * L // 4):
+            ts = sorted(timed_steps(1, S0, n, "cat", raw=True)[0])
+            med = 0.5 * (ts[(n - 1) // 2] + ts[n // 2])
+            pts.append((S0, med))
+            spread = max(spread, (ts[-1] - ts[0]) / med)
+        S = np.array([p[0] for p in pts], dtype=np.float64)
+        Tm = np.array([p[1] for p in pts], dtype=np.float64)
+        s_all = P + 1 + np.arange(steps, dtype=np.float64)
+        total = float(np.interp(s_all, S, Tm).sum())
+        desc = ", ".join(f"S~{int(a)}: {b * 1e3:.0f} ms/step" for a, b in pts) + f"; median of {n} steps per point, piecewise linear, " \
+            f"largest (max - min) / median within a point {spread * 100:.0f} %"
+        return K * steps / total, desc, spread
+
     v_cat, d_cat, r_cat = leg(B, "cat", budget_s * 0.55)
     v_static, d_static, r_static = leg(B, "static", budget_s * 0.35)
-    v_b1, d_b1, r_b1 = leg(1, "cat", budget_s * 0.1)
+    v_b1, d_b1, r_b1 = leg_b1()
     out = {
         "value": round(v_cat, 2), "unit": "codec tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
         "static_kv_value": round(v_static, 2), "batch1_value": round(v_b1, 2),
-        "fit_max_rel_residual": {"cat": round(r_cat, 4), "static": round(r_static, 4), "batch1": round(r_b1, 4)},
+        "fit_max_rel_residual": {"cat": round(r_cat, 4), "static": round(r_static, 4)},
+        "batch1_step_spread": round(r_b1, 4),
         "sample": (f"decode loop only (no T5/DAC), fp32, {cores} torch threads, each leg = per-step times sampled along the run, "
                    f"fitted in S and integrated over {steps} steps: value = B={B} reference-shaped cat-grown KV [{d_cat}]; "
                    f"static_kv_value = B={B} preallocated KV [{d_static}]; batch1_value = B=1 cat-grown [{d_b1}]"),
@@ -215,6 +241,113 @@ def dp_report(dist, world, coll_dev, phase, timings, steps, value, root=ROOT):
     return rep
 
 
+class _PlumbingModel:
+    """``--plumbing-only``: stands for the model so that everything AROUND it in an N > 1 run - the self-launch, the process
+    group, the scatter of the id slices, the padded gather, the rank-0 JSON line - can be rehearsed on CPU ranks
+    (tests/test_bench_launcher_cpu.py).  It does no GPU work and times nothing real: the line it yields carries
+    ``"value": 0.0`` and ``"invalid"``, so it cannot be read as a measurement."""
+
+    class _Prof:
+        algo_bytes = total_ms = launches = step_ms = steps = 0
+
+    class _Eng:
+        def profile_read(self, reset=True):
+            return _PlumbingModel._Prof()
+
+    def __init__(self, cfg):
+        self.cfg, self.phase_times, self.profile_every, self.last_codes, self.audio_encoder = cfg, None, 0, None, None
+
+    def engine(self):
+        return self._Eng()
+
+    def generate(self, input_ids, attention_mask=None, prompt_input_ids=None, max_length=None, **kw):
+        K = self.cfg.decoder.num_codebooks
+        base = (input_ids.sum(dim=1) + prompt_input_ids.sum(dim=1)).view(-1, 1, 1)
+        self.last_codes = ((base + torch.arange(K).view(1, K, 1) + 5 * torch.arange(max_length - K).view(1, 1, -1)) % 1024)[None]
+        if self.phase_times is not None:
+            self.phase_times["decode_ms"] += 1.0
+        return None
+
+
+def launch_ranks(args, argv):
+    """``python bench.py --gpus N`` (N > 1) outside a launcher: start ``python -m torch.distributed.run --nproc-per-node N
+    bench.py <same arguments>`` as a CHILD process - this process has not touched a GPU (``torch.cuda.device_count()`` does not
+    initialise one on this image) and never will - relay the ranks' output, print rank 0's JSON line LAST and return the
+    child's return code.  Fewer than N devices (and no PTTS_SHARE_GPU rehearsal): return 2 with a message, measure nothing."""
+    import socket
+    import subprocess
+
+    if not args.plumbing_only and not os.environ.get("PTTS_SHARE_GPU"):
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} asked for, {n_dev} GPU(s) visible: refusing to measure fewer ranks than requested "
+                  f"(PTTS_SHARE_GPU=1 PTTS_DIST_BACKEND=gloo rehearses the N-rank path on one card)", file=sys.stderr, flush=True)
+            return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for line in proc.stdout:
+        t = line.strip()
+        if t.startswith("{") and t.endswith("}") and '"metric"' in t:
+            line_json = t                                    # held back: it is the LAST line this process prints
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited 0 without a JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
+def fp32_parity_pass(cfg, sd, dev, desc, amask, prompt, B, T, P, L, bf16_codes):
+    """north_star asks for bit-exact token ids; those hold in the engine's fp32 parity mode (tests/test_gpu_parity.py:
+    ids equal to the reference's over 2579 steps at this very shape), while `value` is measured in bf16.  What the bit-exact
+    mode costs: ONE timed full generate() pass in fp32 on the same inputs (engine built and a 40-column pass run untimed
+    first: allocation, weight re-tiling, graph capture), plus how far the bf16 pass's codec ids are from the fp32 ones."""
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+
+    K = cfg.decoder.num_codebooks
+    m32 = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device=dev)
+    m32.audio_encoder
+    m32.engine(B, T, P, L)
+    m32.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=40)
+    torch.cuda.synchronize(dev)
+    phase = {"t5_prefill_ms": 0.0, "decode_ms": 0.0, "post_ms": 0.0}
+    m32.phase_times = phase
+    t0 = time.perf_counter()
+    m32.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    n_steps = L - 1
+    out = {"dtype": "fp32", "passes": 1, "tokens_per_s": round(B * K * n_steps / dt, 1), "ms_per_pass": round(dt * 1e3, 2),
+           "decode_ms_per_step": round(phase["decode_ms"] / n_steps, 4),
+           "decode_loop_tokens_per_s": round(B * K * n_steps / (phase["decode_ms"] / 1e3), 1),
+           "phase_ms": {k: round(v, 2) for k, v in phase.items()},
+           "decode_loop_roofline": decode_loop_roofline(cfg.decoder, B, T, P, n_steps, 4, phase["decode_ms"] / 1e3),
+           "parity": "ids bit-exact vs the reference in this mode: tests/test_gpu_parity.py::test_fp32_long_horizon_against_the_reference"}
+    if bf16_codes is not None:
+        c32, c16 = m32.last_codes[0], bf16_codes[0]
+        same = (c32 == c16)
+        cols = same.all(dim=1)                               # [B, F]: every codebook of the frame equal
+        first = [int((~cols[b]).nonzero()[0]) if not bool(cols[b].all()) else int(cols.shape[1]) for b in range(cols.shape[0])]
+        out["bf16_run_vs_this_run"] = {"ids_equal_frac": round(float(same.float().mean()), 4),
+                                       "first_differing_frame_min_median_max": [min(first), sorted(first)[len(first) // 2], max(first)],
+                                       "frames": int(cols.shape[1]),
+                                       "note": "free-running greedy: after the first flipped argmax a row follows another path"}
+    m32._engine.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,43 +362,71 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full-b1", action="store_true", help="also time one FULL batch-1 run of the CPU port (minutes)")
     ap.add_argument("--no-dac", action="store_true", help="stop at codec ids (diagnostic; not the headline)")
+    ap.add_argument("--no-fp32-pass", action="store_true", help="skip the one timed pass in the bit-exact fp32 mode (N = 1, bf16 runs)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="N = 1 through generate_data_parallel on a world-size-1 process group (runs every collective of "
+                         "distributed.py on RCCL with one rank; not the headline)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="CPU rehearsal of the N-rank plumbing with a stand-in model (gloo, no GPU, no measurement)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    plumbing = args.plumbing_only
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "WORLD_SIZE" not in os.environ:                  # --force-dp outside a launcher: a group of this one process
+            import socket
+
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_PORT=str(sock.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            sock.close()
         # "nccl" is RCCL over xGMI on ROCm.  PTTS_DIST_BACKEND=gloo + PTTS_SHARE_GPU=1 rehearse the N>1 path on
         # a single-GPU box (all ranks on cuda:0, collectives through host memory).
-        backend = os.environ.get("PTTS_DIST_BACKEND", "nccl")
+        backend = "gloo" if plumbing else os.environ.get("PTTS_DIST_BACKEND", "nccl")
         if os.environ.get("PTTS_SHARE_GPU"):
             local_rank = 0
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from parler_tts_amd.configuration import mini_v01_config
-    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
-    from parler_tts_amd.weights import synthetic_state_dict
 
     cfg = mini_v01_config()
     B, T, P, L = args.batch, args.desc_len, args.prompt_len, args.max_length
     K = cfg.decoder.num_codebooks
-    sd = synthetic_state_dict(cfg, seed=1234, never_eos=True)
-    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=args.dtype, device=dev)
-    model.profile_every = args.profile_every
+    if plumbing:
+        dev, sd = torch.device("cpu"), None
+        model = _PlumbingModel(cfg)
+    else:
+        from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+        from parler_tts_amd.weights import synthetic_state_dict
+
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        sd = synthetic_state_dict(cfg, seed=1234, never_eos=True)
+        model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=args.dtype, device=dev)
+        model.profile_every = args.profile_every
     # weak scaling: the job's batch is B utterances per GPU.  For N > 1 the whole batch lives on rank 0 and travels through
-    # parler_tts_amd.distributed.generate_data_parallel - broadcast of the id tensors, contiguous slices, local generate(),
+    # parler_tts_amd.distributed.generate_data_parallel - scatter of the id slices, local generate(),
     # gather of the codec ids with per-row lengths - i.e. the API a multi-GPU user calls, inside the timed region.
     desc, prompt = synth_inputs(cfg, B * world, T, P, seed=1234)
     desc, prompt = desc.to(dev), prompt.to(dev)
@@ -280,10 +441,12 @@ def main():
     one_pass = make_one_pass(model, cfg, desc, amask, prompt, kw, dist, rank, world, dev, coll_dev, B, L, timings)
 
     def sync_all():
-        torch.cuda.synchronize(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
 
     out = None
     for _ in range(args.warmup):
@@ -302,7 +465,7 @@ def main():
     # every timed pass ran the same inputs greedily: their codec ids must be identical (bit-repeatability check)
     repeatable = all(bool(torch.equal(c, pass_codes[0])) for c in pass_codes[1:]) if len(pass_codes) > 1 else None
     if dist is not None:
-        tmax = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        tmax = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -311,7 +474,7 @@ def main():
     F = L - K
     audio_s = B * F / cfg.audio_encoder.frame_rate * args.steps * world
     prof = model.engine().profile_read(reset=True)
-    dp = dp_report(dist, world, coll_dev, phase, timings, args.steps, tokens / dt) if dist is not None else None
+    dp = dp_report(dist, world, coll_dev, phase, timings, args.steps, 0.0 if plumbing else tokens / dt) if dist is not None else None
     if rank == 0:
         achieved = (prof.algo_bytes / 1e9) / (prof.total_ms / 1e3) if prof.total_ms > 0 else 0.0
         # HBM traffic of the dominant kernel: NOT a counter reading of this run.  rocprofv3 --pmc passes (separate runs,
@@ -330,13 +493,13 @@ def main():
                 traffic = None
         line = {
             "metric": "codec tokens/sec + real-time-factor, parler_tts_mini_v0.1 greedy @ bs32",
-            "value": round(tokens / dt, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
+            "value": 0.0 if plumbing else round(tokens / dt, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "none (plumbing rehearsal)" if plumbing else "synthetic",
             "config": {"workload": f"parler_tts_mini_v0.1 {args.dtype}, batch {B}/GPU greedy, T={T} P={P} max_length={L} "
                                    f"({n_steps} decode steps), full generate() incl. T5 encoder, prefill and DAC decode"
                                    + (" [DAC skipped]" if args.no_dac else "")
-                                   + ("" if world == 1 else "; whole batch on rank 0 -> generate_data_parallel (scatter id "
+                                   + ("" if dist is None else "; whole batch on rank 0 -> generate_data_parallel (scatter id "
                                       "slices, local generate, gather codec ids)"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "rtf_audio_s_per_wall_s": round(audio_s / dt, 2),
@@ -385,8 +548,15 @@ def main():
                 "counters": "profiles/r03_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
         if dp is not None:
             line["data_parallel"] = dp
+        if plumbing:
+            line["invalid"] = "--plumbing-only: stand-in model on CPU ranks, nothing was measured"
+            for k in ("rtf_audio_s_per_wall_s", "decode_loop_tokens_per_s", "ttft_ms_rank0", "decode_loop_roofline_rank0", "roofline",
+                      "dac_decode_rank0", "phase_ms_per_step_rank0"):
+                line.pop(k, None)
         line["profile_every"] = args.profile_every    # every n-th decode step of the timed region runs eagerly with events
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and args.dtype == "bf16" and not (args.no_fp32_pass or plumbing or args.no_dac or args.force_dp):
+            line["fp32_parity_mode"] = fp32_parity_pass(cfg, sd, dev, desc, amask, prompt, B, T, P, L, pass_codes[-1] if pass_codes else None)
+        if world == 1 and not (args.no_cpu_baseline or plumbing or args.force_dp):
             sd_dec = {k: v for k, v in sd.items() if not k.startswith(("text_encoder.", "audio_encoder."))}
             line["cpu_baseline"] = cpu_baseline(cfg, sd_dec, B, T, P, L, full_b1=args.cpu_full_b1)
             if line["decode_loop_tokens_per_s"]:

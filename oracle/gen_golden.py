@@ -375,6 +375,64 @@ def bf16_long_case(name="minilong_greedy"):
     save(name + "_bf16", **out)
 
 
+def ref_bf16_cases(names=("mini_greedy", "mini_greedy_ragged", "minilong_greedy")):
+    """The REAL reference run in bfloat16: the benchmark precision gets a reference-held accuracy
+    statement.  The reference computes in the model dtype (softmax M:342, sinusoid table cast M:213; half precision is chosen
+    at training/run_parler_tts_training.py:800-803), so ``model.to(torch.bfloat16)`` on CPU under the shim IS the reference's
+    own bf16 arithmetic.  Per committed fp32 fixture, teacher-forced along its raw ids:
+      * fp32 again (must reproduce the fixture's ids bitwise; gives the fp32 logits at every recorded step),
+      * bf16 decoder behind the fixture's fp32 T5 states cast to bf16 (what the engine's teacher-forced tests are fed),
+      * bf16 end to end (T5 in bf16 too),
+    and kept: the logits (float32 copies) of the recorded steps, the model's own argmax of EVERY step, its top-2 margins,
+    and the summary numbers the GPU test compares the bf16 engine with (max / mean |delta| vs the reference's own fp32
+    logits, argmax agreement over the kept positions)."""
+    from tests.helpers import case_inputs, free_positions, load_case, state_dict_for
+
+    for name in names:
+        f, meta = load_case(name)
+        cfg, sd = state_dict_for(name, meta)
+        model = ref_shim.build_reference_model(cfg, sd)
+        desc, amask, prompt, pmask = case_inputs(f)
+        gold = torch.from_numpy(f["raw_ids"])
+        L = int(f["max_length"])
+        forced = {s: gold[:, s + 1] for s in range(L - 1)}
+        steps = frozenset(range(L - 1)) if L <= 32 else frozenset(int(x) for x in f["logit_steps"])
+        enc32 = torch.from_numpy(f["enc_t5"])
+        kw = dict(record_logits=steps, forced_tokens=forced)
+        r32 = ref_shim.reference_generate_ids(model, desc, amask, prompt, pmask, L, **kw)
+        assert torch.equal(r32["raw_ids"], gold) and torch.equal(r32["enc_t5"], enc32), "the fp32 re-run left the fixture"
+        assert torch.equal(r32["own"], gold[:, 1:].T), "fp32 greedy choices differ from the fixture's ids"
+        model = model.to(torch.bfloat16)
+        rb = ref_shim.reference_generate_ids(model, desc, amask, prompt, pmask, L, encoder_states=enc32.to(torch.bfloat16), **kw)
+        rf = ref_shim.reference_generate_ids(model, desc, amask, prompt, pmask, L, **kw)
+        free = torch.from_numpy(free_positions(f["pattern"], L - 1))
+        out = dict(logit_steps=np.array(sorted(steps)))
+        if L <= 32:      # the short fixtures keep the fp32 logits of their first steps only: all steps here
+            out["step_logits_fp32"] = r32["step_logits"]
+        else:            # the long ones hold these very steps already: not stored twice
+            assert np.array_equal(f["logit_steps"], out["logit_steps"]) and np.array_equal(f["step_logits"], r32["step_logits"].numpy())
+        assert np.array_equal(f["margins"], r32["margins"].numpy())
+        summary = {}
+        for tag, r in (("bf16", rb), ("bf16_full", rf)):
+            d = (r["step_logits"] - r32["step_logits"]).abs()
+            agree = (r["own"] == r32["own"])[free].float().mean()
+            summary[tag] = dict(max_abs_dlogit=float(d.max()), mean_abs_dlogit=float(d.mean()), argmax_agreement=float(agree),
+                                steps_compared=int(d.shape[0]), argmaxes_compared=int(free.sum()))
+            # bf16 values: the upper 16 bits of their float32 copies are the whole number (tests/helpers.bf16_bits_to_float)
+            bits = r["step_logits"].contiguous().view(torch.int32)
+            assert bool((bits & 0xFFFF).eq(0).all()), "a recorded bf16 logit is not a bf16 value"
+            out["step_logits_" + tag + "_bits"] = (bits >> 16).to(torch.int16)
+            out["own_" + tag] = r["own"].to(torch.int16)
+            out["margins_" + tag] = r["margins"]
+            print(f"  {name} [{tag}]: max |dlogit| {float(d.max()):.4f} mean {float(d.mean()):.5f} argmax agreement "
+                  f"{float(agree) * 100:.2f} % of {int(free.sum())}")
+        out["enc_t5_bf16_full"] = rf["enc_t5"].float()
+        out["meta"] = json.dumps(dict(source=name, summary=summary,
+                                      how="reference model.to(torch.bfloat16) on CPU under oracle/ref_shim, teacher-forced along the fp32 fixture's raw ids"))
+        save(name + "_refbf16", **out)
+        del model
+
+
 def nrs_case():
     """num_return_sequences = 2 under sampling (M:2600-2606): the reference's own expansion (third-party
     `_expand_inputs_for_generation`) of the id rows, the kwargs and the stashed delay pattern; teacher-forced fixture
@@ -442,6 +500,11 @@ def main():
     if "--only-dac-long" in sys.argv:
         torch.set_num_threads(8)
         dac_long_cases()
+        return
+    if "--only-ref-bf16" in sys.argv:
+        torch.set_num_threads(8)
+        names = [a for a in sys.argv[1:] if not a.startswith("--")]
+        ref_bf16_cases(*([tuple(names)] if names else []))
         return
     if "--only-nrs" in sys.argv:
         nrs_case()

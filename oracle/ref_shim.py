@@ -114,12 +114,15 @@ def build_reference_model(cfg, state_dict):
 def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, prompt_attention_mask,
                            max_length, do_sample=False, temperature=1.0, top_k=50, guidance_scale=None,
                            generator=None, record_logits=0, forced_tokens=None, decoder_input_ids=None,
-                           decoder_attention_mask=None, num_return_sequences=1):
+                           decoder_attention_mask=None, num_return_sequences=1, encoder_states=None):
     """Drive the REAL reference ``forward`` (M:1927) + ``prepare_inputs_for_generation`` (M:2081) +
     ``build/apply_delay_pattern_mask`` with the third-party greedy/sample step restated in a few lines
     (transformers 4.3x ``greedy_search``/``sample`` no longer exist).
     Then the un-delay of M:2633-2648 using the reference's own functions.
-    ``record_logits``: an int n (the first n steps) or a set of step indices (long runs keep a sample)."""
+    ``record_logits``: an int n (the first n steps) or a set of step indices (long runs keep a sample).
+    ``encoder_states``: text-encoder output handed in (as ``generate(encoder_outputs=...)`` allows, M:2226) instead of running
+    the model's own T5 - used to put a bfloat16 decoder behind the SAME encoder states an fp32 run saw.
+    The model may have been cast with ``.to(torch.bfloat16)``: logits are recorded as float32 copies of what it returns."""
     from transformers.modeling_outputs import BaseModelOutput
 
     dec = model.decoder.config
@@ -127,7 +130,10 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
     B = input_ids.shape[0]
     if attention_mask is None:
         attention_mask = torch.ones_like(input_ids)
-    enc = model.text_encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+    if encoder_states is None:
+        enc = model.text_encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+    else:
+        enc = encoder_states.clone()
     enc_t5 = enc.clone()
     use_cfg = guidance_scale is not None and guidance_scale > 1
     amask = attention_mask
@@ -165,12 +171,12 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
     start_ids = ids[:, :1].clone() if decoder_input_ids is None else None
     unf = torch.ones(ids.shape[0], dtype=torch.long)
     past = None
-    step_logits, margins, step = [], [], 0
+    step_logits, margins, owns, step = [], [], [], 0
     while True:
         mi = model.prepare_inputs_for_generation(ids, past_key_values=past, decoder_delay_pattern_mask=pattern, **kw)
         out = model(**mi, return_dict=True)
         past = out.past_key_values
-        logits = out.logits[:, -1, :]
+        logits = out.logits[:, -1, :].float()        # transformers >= 4.4x selects on an fp32 copy of the last row
         if use_cfg:
             n = logits.shape[0] // 2
             logits = logits[n:] + (logits[:n] - logits[n:]) * guidance_scale
@@ -186,6 +192,7 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
             t2 = torch.topk(logits, 2, dim=-1)[0]
             margins.append(t2[:, 0] - t2[:, 1])
             nxt = torch.argmax(logits, dim=-1)
+            owns.append(nxt.clone())
         if forced_tokens is not None and step in forced_tokens:
             nxt = forced_tokens[step].clone()
         nxt = nxt * unf + dec.pad_token_id * (1 - unf)
@@ -208,6 +215,7 @@ def reference_generate_ids(model, input_ids, attention_mask, prompt_input_ids, p
         res["step_logits"] = torch.stack(step_logits)
     if margins:
         res["margins"] = torch.stack(margins)
+        res["own"] = torch.stack(owns)        # the model's own argmax of every step, before any forcing
     return res
 
 

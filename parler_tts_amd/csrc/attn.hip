@@ -103,6 +103,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
     // The loads that feed the context length and the query are stated FIRST, so that they are older than the key tiles
     // below (vector-memory results return in issue order: a flag queued behind an HBM tile would wait for it).
     int pos_ld = 0;
+    // scalar_load invariant (ptts_common.h): this kernel writes neither StepState nor the finished flags (advance / select do)
     if (a.len_from_state) pos_ld = scalar_load_int(&a.state->pos);
     int uflag[16];               // scalar loads too (the flag array is over-allocated by 16 ints: engine.hip)
 #pragma unroll
@@ -151,6 +152,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
         int alive = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) alive |= k < a.alive_k ? uflag[k] : 0;
+        // codebooks 16 .. 31 (ptts_create accepts up to 32; under the delay pattern the HIGHEST codebooks finish last): a tail
+        // of scalar loads that a model with <= 16 codebooks never enters
+        for (int k = 16; k < a.alive_k; ++k) alive |= scalar_load_int(a.unfinished + (bu % a.alive_b) * a.alive_k + k);
         if (!alive) S = 1;
     }
 
@@ -410,6 +414,7 @@ __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     }
     // (a table entry is uniform per wave: read through the scalar cache, it does not join the vector-memory queue - a
     // conditional vector load here made hipcc drain vmcnt in front of the tiles)
+    // scalar_load invariant: the block table is host-written, bias_flag by build_bias_kernel at prefill; never by this kernel
     const int page = a.pool.block_table ? scalar_load_int(a.pool.block_table + bu * a.pool.max_blocks) : bu * a.pool.max_blocks;
     const elem_t* kp = pool + (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() +
                        (size_t)page * a.pool.page_elems() + c * EPL;

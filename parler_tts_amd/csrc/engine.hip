@@ -970,7 +970,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->cross_masked, sizeof(int) * 4);
     A(e->enc_h, sizeof(float) * ((size_t)Bm * cfg->max_desc_len + 32) * D);
     A(e->tok_in, sizeof(int) * rows * K);
-    A(e->unfinished, sizeof(int) * (rows * K + 16));     // + 16: the attention kernel reads 16 flags from an utterance's first one
+    A(e->unfinished, sizeof(int) * (rows * K + 32));     // + 32: the attention kernel reads 16 flags from an utterance's first one, whatever K is
     A(e->force, sizeof(long long) * rows * K);
     A(e->state, sizeof(StepState));
     if (cfg->t5_layers > 0) {
@@ -1007,8 +1007,11 @@ int ptts_destroy(ptts_engine* e) {
     drop_graph(e);
     if (e->dac_buf0) (void)hipFree(e->dac_buf0);
     if (e->dac_buf1) (void)hipFree(e->dac_buf1);
-    for (void* p : {(void*)e->pf.x, (void*)e->pf.q, (void*)e->pf.xstat, e->pf.attn_frag, e->pf.mlp_frag, e->pf.x_frag, e->pf.x_frag2})
+    for (void* p : {(void*)e->pf.x, (void*)e->pf.q, (void*)e->pf.xstat, (void*)e->pf.ffn_raw, e->pf.attn_frag, e->pf.mlp_frag, e->pf.x_frag, e->pf.x_frag2})
         if (p) (void)hipFree(p);
+#ifdef PTTS_STAMPS
+    if (e->stamps) (void)hipFree(e->stamps);
+#endif
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (void* p : e->allocs) (void)hipFree(p);

@@ -183,7 +183,7 @@ __device__ inline void epilogue(const GemmArgs& a, int epi, int row, int n, f32x
             int b, tok;
             if (epi == EPI_QKV_SELF) {
                 if (a.npos > 0) { b = row / a.npos; tok = a.pos0 + (row - b * a.npos); }
-                else { b = row; tok = scalar_load_int(&a.state->pos); }     // scalar cache: no wait on the vector-memory queue
+                else { b = row; tok = scalar_load_int(&a.state->pos); }     // scalar cache: no wait on the vector-memory queue (invariant: no gemm launch writes StepState)
             } else { b = row / a.T; tok = row - b * a.T; }
             elem_t* c = reinterpret_cast<elem_t*>(a.pool.base) +
                         a.pool.elem_off(b, a.layer, kv, nn >> 6, tok) + (nn & 63);
@@ -312,11 +312,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             have_res = true;
         }
     }
+    // FOLD with NB > 1 (LM heads: three feature blocks per workgroup, 204 workgroups instead of 612 whose starts spread over
+    // 6.6 us of the launch - round-3 stamps, slot 168): thread t finishes item t (feature block i = t / (64 H2)), so it holds
+    // that block's fold constants; one item per thread
+    static_assert(!FOLD || NB * 64 * H2 <= NW * 64, "folded epilogue: one item per thread");
     float4 c1v = make_float4(0, 0, 0, 0), c2v = make_float4(0, 0, 0, 0);
-    if (FOLD && tid < 64 * H2) {
-        const int n = nb0 * 16 + 4 * ((tid & 63) >> 4);
-        c1v = *reinterpret_cast<const float4*>(a.c1 + n);
-        c2v = *reinterpret_cast<const float4*>(a.c2 + n);
+    if (FOLD && tid < NB * 64 * H2) {
+        const int n = (nb0 + (H2 == 2 ? (tid >> 7) : (tid >> 6))) * 16 + 4 * ((tid & 63) >> 4);
+        if (n < a.N) {
+            c1v = *reinterpret_cast<const float4*>(a.c1 + n);
+            c2v = *reinterpret_cast<const float4*>(a.c2 + n);
+        }
     }
     float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};
     // bf16 folded path: the row statistics come from the matrix cores - ones . x (every output row = the column sums) and
@@ -672,6 +678,11 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
             } while (0)
             if (a.epi == EPI_QKV_SELF) PTTS_FOLD_INST(EPI_QKV_SELF, ACT_NONE);
             if (a.epi == EPI_ACT_FRAG && a.act == ACT_GELU) PTTS_FOLD_INST(EPI_ACT_FRAG, ACT_GELU);
+            // LM heads (N = K * V = 9792 = 204 x 48): three feature blocks per workgroup.  Same k-split, same wave order, same
+            // statistics as the one-block instance: bit-identical (PTTS_GEMM_NO_NB3=1 for the A/B and the equivalence test)
+            if (P::IS_BF16 && a.epi == EPI_ROWMAJOR && a.act == ACT_NONE && tiles == 4 && a.N % 48 == 0 && a.N >= 4096 &&
+                getenv("PTTS_GEMM_NO_NB3") == nullptr)
+                return launch_one<P, 8, 3, false, 1, 2, true, EPI_ROWMAJOR, ACT_NONE, 0, 4>(a, stream);
             if (a.epi == EPI_ROWMAJOR && a.act == ACT_NONE) PTTS_FOLD_INST(EPI_ROWMAJOR, ACT_NONE);
 #undef PTTS_FOLD_INST
         }

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void embed_codebooks_kernel(EmbedArgs a) {
     const int b = blockIdx.x;
     // the step's position and this utterance's K token ids are uniform per workgroup: scalar-cache reads (no vector round trip,
     // no LDS hand-over, no barrier in front of the row gathers)
+    // scalar_load invariant (ptts_common.h): the embed kernel writes neither StepState nor tok_in (advance / select do, a launch earlier)
     const int pos = scalar_load_int(&a.state->pos);
     int toks[16];
 #pragma unroll
@@ -167,6 +168,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     __shared__ unsigned sel_prefix, sel_remaining;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int V = a.vocab;          // valid ids; rows are a.V (= padded stride) apart
+    // scalar_load invariant: select_kernel never writes StepState (advance_kernel does, in the launch behind it); the words it DOES
+    // write - tok_in, unfinished - it reads with plain loads
     const int cur = scalar_load_int(&a.state->cur_len);      // scalar cache: the logits loads below do not queue behind it
     if (cur >= a.L) return;
     const float* lg = a.logits + (size_t)row * a.V;

@@ -117,10 +117,24 @@ struct StepState {
 // Read through a constant-address-space pointer they become scalar loads (s_load_dword: the scalar cache starts cold at every
 // launch, so the value is the current one), which neither wait for nor delay the vector-memory stream - a plain `state->pos`
 // compiles to a global_load + s_waitcnt vmcnt(0) in front of everything queued behind it.
+//
+// INVARIANT (every call site repeats it in one line): address space 4 tells LLVM the word is CONSTANT for the kernel, so a
+// kernel may read a word this way only if NO launch of that kernel writes it - neither the reading workgroup nor any other
+// workgroup of the same dispatch - and the value was written by an EARLIER dispatch on the same stream (the scalar cache is
+// invalidated at every dispatch boundary, not inside one).  A fused kernel that both advances the loop state and reads it
+// (the reverted merged tail of DESIGN_HISTORY.md) must use plain loads for those words.  Writers today: advance_kernel
+// (StepState), select_kernel (tok_in, unfinished), build_bias_kernel (bias_flag), the host (block_table); readers: the attention,
+// gemm-append, embed and select kernels - never a writer of the word it reads.  `make CXXFLAGS+=-DPTTS_PLAIN_STATE_LOADS`
+// builds the same library with ordinary global loads for an A/B of ids (tests need no change).
 typedef const int __attribute__((address_space(4))) ptts_cint;
-__device__ inline int scalar_load_int(const int* p) { return *reinterpret_cast<ptts_cint*>(reinterpret_cast<uintptr_t>(p)); }
 typedef const float __attribute__((address_space(4))) ptts_cfloat;
+#ifdef PTTS_PLAIN_STATE_LOADS
+__device__ inline int scalar_load_int(const int* p) { return __builtin_nontemporal_load(p); }
+__device__ inline float scalar_load_float(const float* p) { return __builtin_nontemporal_load(p); }
+#else
+__device__ inline int scalar_load_int(const int* p) { return *reinterpret_cast<ptts_cint*>(reinterpret_cast<uintptr_t>(p)); }
 __device__ inline float scalar_load_float(const float* p) { return *reinterpret_cast<ptts_cfloat*>(reinterpret_cast<uintptr_t>(p)); }
+#endif
 
 // ---- K-split hand-over stores --------------------------------------------------------------------------------
 // MFMA accumulators go to LDS through PLAIN C++ stores, never through an `asm` statement: hipcc pads the gfx950

@@ -39,17 +39,27 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
 
 def _meta_tensor(tensors: Dict[str, Optional[torch.Tensor]], names, device) -> torch.Tensor:
     """fixed-size description of the named tensors: per name [present, dtype code, ndim, dims...] (no pickling, so the
-    exchange is one small int64 broadcast on the collective's own device)"""
+    exchange is one small int64 broadcast on the collective's own device).  A tensor the scatter cannot carry (more than
+    _MAX_DIMS dims, 0-dim, a dtype outside _DTYPES) is encoded as present = -1 and NOT raised here: only the source rank runs
+    this function, in front of a broadcast the other ranks have already entered; `_check_meta` raises on every rank after it."""
     rows = []
     for k in names:
         v = tensors.get(k)
         if v is None:
             rows.append([0] * (3 + _MAX_DIMS))
-            continue
-        if v.dim() > _MAX_DIMS or v.dim() < 1 or v.dtype not in _DTYPES:
-            raise ValueError(f"{k}: unsupported tensor for the batch scatter (shape {tuple(v.shape)}, {v.dtype})")
-        rows.append([1, _DTYPES.index(v.dtype), v.dim()] + list(v.shape) + [0] * (_MAX_DIMS - v.dim()))
+        elif v.dim() > _MAX_DIMS or v.dim() < 1 or v.dtype not in _DTYPES:
+            rows.append([-1, -1, min(v.dim(), _MAX_DIMS)] + list(v.shape[:_MAX_DIMS]) + [0] * (_MAX_DIMS - min(v.dim(), _MAX_DIMS)))
+        else:
+            rows.append([1, _DTYPES.index(v.dtype), v.dim()] + list(v.shape) + [0] * (_MAX_DIMS - v.dim()))
     return torch.tensor(rows, dtype=torch.int64, device=device)
+
+
+def _check_meta(names, meta) -> None:
+    """after the broadcast: the same meta on every rank, so every rank raises (or none does)"""
+    bad = [k for k, m in zip(names, meta) if m[0] < 0]
+    if bad:
+        raise ValueError(f"{', '.join(bad)}: unsupported tensor for the batch scatter (1 to {_MAX_DIMS} dims, dtypes "
+                         f"{[str(d).replace('torch.', '') for d in _DTYPES]})")
 
 
 def scatter_inputs(tensors: Dict[str, Optional[torch.Tensor]], src: int = 0, device=None, group=None):
@@ -61,6 +71,7 @@ def scatter_inputs(tensors: Dict[str, Optional[torch.Tensor]], src: int = 0, dev
     meta = _meta_tensor(tensors, names, device) if rank == src else torch.zeros((len(names), 3 + _MAX_DIMS), dtype=torch.int64, device=device)
     dist.broadcast(meta, src=src, group=group)
     meta = meta.cpu().tolist()
+    _check_meta(names, meta)
     total = max([m[3] for m in meta if m[0]] + [0])
     per = max(shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)) if total else 0
     lo, hi = shard_bounds(total, world, rank)
@@ -95,8 +106,10 @@ def broadcast_inputs(tensors: Dict[str, Optional[torch.Tensor]], src: int = 0, d
     names = sorted(tensors.keys())
     meta = _meta_tensor(tensors, names, device) if rank == src else torch.zeros((len(names), 3 + _MAX_DIMS), dtype=torch.int64, device=device)
     dist.broadcast(meta, src=src, group=group)
+    meta = meta.cpu().tolist()
+    _check_meta(names, meta)
     out = {}
-    for k, m in zip(names, meta.cpu().tolist()):
+    for k, m in zip(names, meta):
         if not m[0]:
             out[k] = None
             continue

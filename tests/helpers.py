@@ -49,3 +49,8 @@ def forced_tokens(f):
 def free_positions(pattern, steps):
     """[steps, rows] bool: the token produced at step j (column j+1) is kept by the delay pattern"""
     return (pattern[:, 1:1 + steps] == -1).T
+
+
+def bf16_bits_to_float(bits):
+    """int16 array holding the upper halves of float32 words (how the *_refbf16 fixtures store bfloat16 logits) -> float32"""
+    return (bits.astype(np.int32) << 16).view(np.float32)

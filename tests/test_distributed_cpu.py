@@ -217,3 +217,44 @@ def test_a_wrong_row_count_raises_on_every_rank_instead_of_hanging():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == {0: "ValueError", 1: "ValueError"}
+
+
+def _unsupported_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from parler_tts_amd.distributed import broadcast_inputs, scatter_inputs
+
+    ids, mask, prompt = _inputs(4)
+    got = []
+    for fn in (scatter_inputs, broadcast_inputs):
+        for bad in (ids.reshape(4, 1, 1, 1, 6), ids.to(torch.complex64)):      # 5 dims; a dtype the wire does not carry
+            t = dict(input_ids=bad, attention_mask=mask) if rank == 0 else dict(input_ids=None, attention_mask=None)
+            try:
+                fn(t, src=0, device="cpu")
+                got.append("no error")
+            except ValueError:
+                got.append("ValueError")
+    # the group is still usable: nobody is stuck inside a collective
+    mine, total = scatter_inputs(dict(input_ids=ids if rank == 0 else None), src=0, device="cpu")
+    got.append((total, tuple(mine["input_ids"].shape)))
+    out_q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_an_unsupported_tensor_on_the_source_rank_raises_on_every_rank_instead_of_hanging():
+    """_meta_tensor used to raise on the source rank alone, in front of a broadcast the others were already in."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unsupported_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r][:4] == ["ValueError"] * 4 and got[r][4] == (4, (2, 6))

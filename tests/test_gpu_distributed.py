@@ -1,0 +1,21 @@
+"""The data-parallel plumbing on the REAL backend: a world-size-1 RCCL group on cuda:0 in a child process (one GPU per box here;
+RCCL refuses two ranks on one device, so rank counts > 1 are covered by the gloo tests and by the driver's SCALE run)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_every_collective_of_the_dp_path_runs_on_rccl_world_size_1():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on an MI355X box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_rccl_child.py")], capture_output=True, text=True, env=env,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
