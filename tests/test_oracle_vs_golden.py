@@ -344,3 +344,47 @@ def test_dac_encode_oracle_matches_hf_dac_fixture(name):
     # and the decode side inverts the quantiser's bookkeeping: from_codes(codes) is the quantised latent the encoder saw
     z = cpu_ref.dac_from_codes(cfg, sd, codes[0])
     assert z.shape == f["latent"].shape
+
+
+def test_the_oracle_in_bfloat16_is_the_reference_in_bfloat16():
+    """`<name>_refbf16` fixtures hold the REAL reference run with `model.to(torch.bfloat16)` (oracle/gen_golden.py
+    --only-ref-bf16).  oracle/cpu_ref.py uses the reference's op order with stock torch ops and follows the dtype of what it is
+    given, so evaluated on bf16 weights and bf16 encoder states it must reproduce those logits - which pins a PORTABLE statement
+    of the reference's bf16 arithmetic (usable on the GPU box, where the reference is absent).  First 5 steps of the ragged
+    mini_v0.1 case (24 layers; ~20 s); bitwise on the machine that wrote the fixture, one bf16 ulp of slack elsewhere."""
+    from tests.helpers import bf16_bits_to_float
+
+    name = "mini_greedy_ragged"
+    f, meta = load_case(name)
+    g, gmeta = load_case(name + "_refbf16")
+    cfg, sd = state_dict_for(name, meta)
+    desc, amask, prompt, pmask = case_inputs(f)
+    gold = torch.from_numpy(f["raw_ids"])
+    n = 5
+    sdb = {k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in sd.items() if not k.startswith("text_encoder.")}
+    seen = []
+
+    class _Enough(Exception):
+        pass
+
+    def grab(ids, scores):          # a logits processor sees every step's scores: keep n of them, then leave the loop
+        seen.append(scores.float().clone())
+        if len(seen) == n:
+            raise _Enough
+        return scores
+
+    try:                            # the fixture's own max_length: the delay pattern depends on it
+        cpu_ref.generate_ids(cfg, sdb, torch.from_numpy(f["enc_t5"]).to(torch.bfloat16), amask, prompt, pmask, int(f["max_length"]),
+                             forced_tokens={s: gold[:, s + 1] for s in range(n)}, logits_processor=[grab])
+    except _Enough:
+        pass
+    got = torch.stack(seen).numpy()
+    want = bf16_bits_to_float(g["step_logits_bf16_bits"])[:n]
+    assert np.array_equal(g["logit_steps"][:n], np.arange(n))
+    assert np.abs(got - want).max() <= 2.0 ** -6, np.abs(got - want).max()          # logits < 4: one bf16 ulp is 2^-6 at most
+    assert (got == want).mean() > 0.99
+    # the fixture's own summary is what its arrays say
+    d = np.abs(bf16_bits_to_float(g["step_logits_bf16_bits"]) - g["step_logits_fp32"])
+    summ = gmeta["summary"]["bf16"]
+    assert abs(float(d.max()) - summ["max_abs_dlogit"]) < 1e-6 and abs(float(d.mean()) - summ["mean_abs_dlogit"]) < 1e-7
+    assert np.abs(g["step_logits_fp32"][: f["step_logits"].shape[0]] - f["step_logits"]).max() == 0.0   # same fp32 run as the base fixture
