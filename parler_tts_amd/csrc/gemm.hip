@@ -20,7 +20,7 @@
 //     rstd * (acc - mean * c1) + c2  (fold_ln_kernel builds W', c1, c2 once per weight set)
 //   * the residual out-projection of the self-attention can carry a second ROLE in the same launch: extra
 //     workgroups compute the look-ahead cross-attention query  [x | a] . [Wq' ; Wq'.Wo]^T  
-//   * code-generation rules learnt the hard way: tile guards must be scalar (MFMA ignores
+//   * code-generation rules learnt the hard way (DESIGN_HISTORY.md section A): tile guards must be scalar (MFMA ignores
 //     EXEC), MFMA results never feed an inline-asm instruction (no hazard padding there), operands of queued
 //     MFMAs keep their own registers
 //
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     // VALU from the B fragments while the weight tiles are still in flight, folded across the four k-groups of a
     // row with two shuffles and across waves through LDS.  (A first version took them from the matrix cores -
     // ones . x and the diagonal of x . x^T; with two processes sharing the GPU those values were occasionally
-    // wrong, about once in 3e4 launches, while the main products never were)
+    // wrong, about once in 3e4 launches, while the main products never were; see DESIGN_HISTORY.md section A.)
     // H2 = 2: the workgroup covers both 16-row halves of the m-tile.  H2 = 1 (fragment input only): one half per
     // workgroup; the two halves of a feature block sit 8 apart in the linear block id, i.e. on the same XCD, so
     // the second read of the block's weights is served by that XCD's L2.

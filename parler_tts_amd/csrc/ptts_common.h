@@ -144,7 +144,7 @@ __device__ inline float scalar_load_float(const float* p) { return *reinterpret_
 // issued these stores as `asm("ds_write_b128 ...; s_waitcnt lgkmcnt(0)")` straight behind the last MFMA of the
 // K loop; tools/check_mfma_asm_hazard.py found 35 (MFMA, asm store) pairs in 9 instances closer than the table
 // allows (8-10 wait states on the shortest path), i.e. a store that can read an accumulator register the matrix
-// pipe has not finished retiring: one register, its last-written lanes - the signature DESIGN.md section 7 records.
+// pipe has not finished retiring: one register, its last-written lanes - the signature DESIGN_HISTORY.md section A records.
 // The lint runs in the CPU test suite and fails on any inline-asm reader of an MFMA result.
 __device__ inline void lds_store_b128(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ inline void lds_store_b32(void* p, float v) { *reinterpret_cast<float*>(p) = v; }

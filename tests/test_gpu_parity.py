@@ -457,7 +457,7 @@ def _ref_bf16_case(name):
 
 # The demand: the bf16 engine's error against the fp32 reference must not exceed the REFERENCE's own bf16 error
 # (factor 1.0).  The engine keeps fp32 accumulators, an fp32 softmax and an fp32 residual stream where the reference rounds every
-# op's output to bf16; measured (round 4, MI355X): max |dlogit| 0.0174-0.0176 against the reference-in-bf16's 0.045-0.049, mean
+# op's output to bf16; measured (round 4, MI355X): max |dlogit| 0.0174-0.0202 against the reference-in-bf16's 0.045-0.049, mean
 # 0.0027-0.0029 against 0.0070-0.0073, i.e. 0.36-0.41 of the reference's own error.  The test asserts 0.6: the demand with a
 # regression guard that still clears the measurement by a third.
 REF_BF16_MAX_FACTOR = 0.6
