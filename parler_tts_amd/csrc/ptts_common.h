@@ -124,7 +124,7 @@ struct StepState {
 // invalidated at every dispatch boundary, not inside one).  A fused kernel that both advances the loop state and reads it
 // (the reverted merged tail of DESIGN_HISTORY.md) must use plain loads for those words.  Writers today: advance_kernel
 // (StepState), select_kernel (tok_in, unfinished), build_bias_kernel (bias_flag), the host (block_table); readers: the attention,
-// gemm-append, embed and select kernels - never a writer of the word it reads.  `make CXXFLAGS+=-DPTTS_PLAIN_STATE_LOADS`
+// gemm-append, embed and select kernels - never a writer of the word it reads.  `make EXTRA=-DPTTS_PLAIN_STATE_LOADS` (into a scratch copy of the objects)
 // builds the same library with ordinary global loads for an A/B of ids (tests need no change).
 typedef const int __attribute__((address_space(4))) ptts_cint;
 typedef const float __attribute__((address_space(4))) ptts_cfloat;
