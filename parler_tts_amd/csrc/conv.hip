@@ -162,6 +162,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // diagnostic build (make CXXFLAGS+=-DPTTS_CONV_STAMPS): wave 0 of every workgroup adds the cycles of each phase of the chunk loop
 // [0] fetch issue  [1] MFMA loop  [2] barrier after it  [3] stash  [4] barrier before the next chunk  [5] chunks  [6] whole kernel
 __device__ unsigned long long g_conv_stamps[16];
+__device__ unsigned long long g_conv_wave[8][8];      // ring kernel, per wave of the workgroup: the six phases summed over workgroups
 #define STAMP(i, t0) do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tacc[i] += t1_ - t0; t0 = t1_; } while (0)
 #else
 #define STAMP(i, t0) do { } while (0)
@@ -611,6 +612,11 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     if (tid == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_stamps[8 + i], tacc[i]);
         atomicAdd(&g_conv_stamps[5], nchunk_done);
+    }
+    if (lane == 0) {      // per wave: waves 0-3 and 4-7 share the SIMDs pairwise and do NOT spend their time alike (profiles/r04_dac_per_wave_stamps.txt)
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_wave[w][i], tacc[i]);
+    }
+    if (tid == 0) {
         atomicAdd(&g_conv_stamps[6], __builtin_amdgcn_s_memtime() - ts_begin);
     }
 #endif
@@ -1320,6 +1326,15 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     const hipError_t e = conv_launch_inner(a, s);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_conv_stamps), sizeof(z));
+    unsigned long long zw[8][8];
+    (void)hipMemcpyFromSymbol(zw, HIP_SYMBOL(g_conv_wave), sizeof(zw));
+    if (z[5] && z[8]) {
+        for (int wv = 0; wv < 8; ++wv)
+            fprintf(stderr, "  wave %d: dma-wait %.0f tap-barrier %.0f issue %.0f mfma %.0f chunk-barrier %.0f stash %.0f\n", wv, (double)zw[wv][0] / z[5],
+                    (double)zw[wv][1] / z[5], (double)zw[wv][2] / z[5], (double)zw[wv][3] / z[5], (double)zw[wv][4] / z[5], (double)zw[wv][5] / z[5]);
+    }
+    static const unsigned long long zero_w[8][8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_wave), zero_w, sizeof(zero_w));
     if (z[5] && z[8])
         fprintf(stderr, "ring stamps Cin=%d N=%d taps=%d dil=%d U=%d: per chunk (cycles) dma-wait %.1f tap-barrier %.1f issue %.1f mfma %.1f chunk-barrier %.1f stash %.1f | chunks %llu kernel/wg %.0f\n",
                 a.Cin, a.N, a.taps, a.tstep, a.U, (double)z[8] / z[5], (double)z[9] / z[5], (double)z[10] / z[5], (double)z[11] / z[5],
