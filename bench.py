@@ -115,24 +115,32 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=34.0, full_b1=False):
     steps = L - 1
 
     def leg(Bx, mode, budget):
-        """per-step time sampled at four cache lengths over the run (start, 1/4, 1/2, 3/4), least-squares quadratic in S
-        (cat-grown: the re-copy and the attention are both linear in S, cache misses bend it upwards), integrated over every
-        step of the run; returns (tokens/s, description, max relative residual of the fit)"""
+        """per-step time at four cache lengths over the run (start, 1/4, 1/2, 3/4) - the MEDIAN of the steps taken at each (6 at the
+        start, 3 elsewhere while the budget lasts, at least 2: one slow step no longer bends the curve) - least-squares quadratic in S
+        (cat-grown: the re-copy and the attention are both linear in S, cache misses bend it upwards), integrated over every step of
+        the run; returns (tokens/s, description, max relative residual of the fit)"""
         import numpy as np
 
-        t0, s0 = timed_steps(Bx, P + 1, 6, mode)
-        pts = [(s0, t0)]
-        # what the later points will cost, from a first look at the middle of the run
-        t_mid, s_mid = timed_steps(Bx, P + L // 2, 2, mode)
+        def med(ts):
+            ts = sorted(ts)
+            return 0.5 * (ts[(len(ts) - 1) // 2] + ts[len(ts) // 2])
+
+        ts0, s0 = timed_steps(Bx, P + 1, 6, mode, raw=True)
+        pts = [(s0, med(ts0))]
+        spent = 7 * pts[0][1]
+        # the middle of the run first: it prices the remaining points
+        tsm, s_mid = timed_steps(Bx, P + L // 2, 3, mode, raw=True)
+        t_mid = med(tsm)
         pts.append((s_mid, t_mid))
-        spent = 7 * t0 + 3 * t_mid
+        spent += 4 * t_mid
         for frac in (0.25, 0.75):
-            est = t0 + (t_mid - t0) * (frac / 0.5)
-            if spent + 3 * est > budget and len(pts) >= 3:
+            est = pts[0][1] + (t_mid - pts[0][1]) * (frac / 0.5)
+            n = 3 if spent + 4 * est <= budget else 2
+            if spent + (n + 1) * est > budget and len(pts) >= 3:
                 break
-            t, sx = timed_steps(Bx, P + int(L * frac), 2, mode)
-            pts.append((sx, t))
-            spent += 3 * t
+            tsx, sx = timed_steps(Bx, P + int(L * frac), n, mode, raw=True)
+            pts.append((sx, med(tsx)))
+            spent += (n + 1) * pts[-1][1]
         pts.sort()
         S = np.array([p[0] for p in pts], dtype=np.float64)
         Tm = np.array([p[1] for p in pts], dtype=np.float64)
@@ -141,7 +149,7 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=34.0, full_b1=False):
         resid = float(np.max(np.abs(np.polyval(coef, S) - Tm) / Tm))
         s_all = P + 1 + np.arange(steps, dtype=np.float64)
         total = float(np.maximum(np.polyval(coef, s_all), Tm.min() * 0.5).sum())
-        desc = ", ".join(f"S~{int(a)}: {b * 1e3:.0f} ms/step" for a, b in pts) + f"; degree-{deg} fit, max residual {resid * 100:.1f} %"
+        desc = ", ".join(f"S~{int(a)}: {b * 1e3:.0f} ms/step" for a, b in pts) + f"; medians, degree-{deg} fit, max residual {resid * 100:.1f} %"
         return Bx * K * steps / total, desc, resid
 
     def leg_b1(n=8):
