@@ -27,6 +27,9 @@
 // while they are staged (after Snake).  256 time rows x TN outputs per 8-wave workgroup, 32-channel chunks.
 #include "ptts_common.h"
 #include "conv.h"
+#ifndef PTTS_CONV_ABLATE
+#define PTTS_CONV_ABLATE 0      // timing-only ablations of conv_kernel_h3r (tools/gpu_calls.md); never in the product build
+#endif
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -495,10 +498,12 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
             if (tid + 512 * k < nx) {
                 const int r = xrow0 + 64 * k;
                 float4 v = (xvalid >> k) & 1 ? xr[k] : make_float4(0, 0, 0, 0);
+#if PTTS_CONV_ABLATE != 3       // 3 = timing-only ablation (WRONG results): the stash without Snake
                 if (snake) {   // Snake(0) = 0, so the zero padding needs no special case
                     v.x = snake_f(v.x, alr.x, inv.x); v.y = snake_f(v.y, alr.y, inv.y);
                     v.z = snake_f(v.z, alr.z, inv.z); v.w = snake_f(v.w, alr.w, inv.w);
                 }
+#endif
                 _Float16 h[4], l[4];
                 split_h(v.x, h[0], l[0]); split_h(v.y, h[1], l[1]); split_h(v.z, h[2], l[2]); split_h(v.w, h[3], l[3]);
                 const int xo = r * LDH + 8 * swz16(r, xq >> 1) + 4 * (xq & 1);
@@ -586,13 +591,21 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
             const size_t wo = (size_t)(lane & 15) * LDH + 8 * swz16(lane & 15, lane >> 4);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
+#if PTTS_CONV_ABLATE == 1       // timing-only ablation (WRONG results): one weight fragment pair per tap instead of NT
+                const half8 bh = *reinterpret_cast<const half8*>(wh + wo), bl = *reinterpret_cast<const half8*>(wl + wo);
+#else
                 const half8 bh = *reinterpret_cast<const half8*>(wh + wo + (size_t)j * 16 * LDH);
                 const half8 bl = *reinterpret_cast<const half8*>(wl + wo + (size_t)j * 16 * LDH);
+#endif
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {            // small terms first, then the leading term
+#if PTTS_CONV_ABLATE == 2       // timing-only ablation (WRONG results): the fragment reads stay, one MFMA instead of three
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh + bl, xfh[i] + xfl[i], acc[i][j], 0, 0, 0);
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, xfh[i], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, xfl[i], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, xfh[i], acc[i][j], 0, 0, 0);
+#endif
                 }
             }
             if (++slot == RS) slot = 0;
