@@ -414,6 +414,15 @@ class ParlerTTSForConditionalGeneration:
             gen = GenerationConfig(**g)
         return cls(cfg, sd, dtype=dtype, device=device, generation_config=gen)
 
+    def save_pretrained(self, path: str) -> None:
+        """Checkpoint directory in the reference layout (config.json, generation_config.json, model.safetensors with the reference's
+        parameter names): what `from_pretrained` reads back, the counterpart of the inherited `PreTrainedModel.save_pretrained`."""
+        from .weights import save_pretrained
+
+        if self._sd is None:
+            raise RuntimeError("no weights to save")
+        save_pretrained(path, self.config, self._sd, self.generation_config)
+
     @classmethod
     def from_synthetic(cls, config: ParlerTTSConfig, seed: int = 0, dtype: str = "bf16", device="cuda:0", **sd_kw):
         return cls(config, synthetic_state_dict(config, seed=seed, **sd_kw), dtype=dtype, device=device)
