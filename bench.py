@@ -187,8 +187,8 @@ def cpu_baseline(cfg, sd, B, T, P, L, budget_s=34.0, full_b1=False):
         "static_kv_value": round(v_static, 2), "batch1_value": round(v_b1, 2),
         "integral_vs_quadratic_fit": {"cat": round(r_cat, 4), "static": round(r_static, 4)},
         "batch1_step_spread": round(r_b1, 4),
-        "sample": (f"decode loop only (no T5/DAC), fp32, {cores} torch threads, each leg = per-step times sampled along the run, "
-                   f"fitted in S and integrated over {steps} steps: value = B={B} reference-shaped cat-grown KV [{d_cat}]; "
+        "sample": (f"decode loop only (no T5/DAC), fp32, {cores} torch threads, each leg = medians of the per-step times at four cache lengths, "
+                   f"piecewise linear in S, integrated over {steps} steps: value = B={B} reference-shaped cat-grown KV [{d_cat}]; "
                    f"static_kv_value = B={B} preallocated KV [{d_static}]; batch1_value = B=1 cat-grown [{d_b1}]"),
     }
     if full_b1:      # one FULL batch-1 run of the port (minutes), not part of the default bench
