@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU box): fp32 engine against oracle/cpu_ref.py on random tiny architectures and call shapes the
+fixtures do not cover - codebooks 1 .. 32, hidden 64 .. 256, 1-3 layers, batch 1 .. 40, descriptions 1 .. 90 tokens, prompts
+0 .. 90 tokens (page crossings at 64), max_length from K + 2 up, ragged masks.  Teacher-forced along the oracle's greedy path:
+logits within 2e-4 and the argmax equal wherever the oracle's top-2 margin exceeds 1e-3.
+    python3 tools/fuzz_parity.py [n_cases] [seed]
+Test infrastructure (imports oracle/ through tests/test_gpu_parity.py's helper); prints one line per case, exits 1 on a failure."""
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from parler_tts_amd.configuration import tiny_config  # noqa: E402
+from parler_tts_amd.weights import synthetic_state_dict  # noqa: E402
+from tests import test_gpu_parity as tg  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+torch.set_num_threads(min(16, os.cpu_count() or 8))
+fails = 0
+for case in range(n_cases):
+    heads = int(rng.integers(1, 5))
+    K = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 16, 17, 24, 32]))
+    layers = int(rng.integers(1, 4))
+    ffn = int(rng.choice([64, 128, 256, 320]))
+    cb = int(rng.choice([32, 64, 128]))
+    B = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 40]))
+    T = int(rng.choice([1, 2, 7, 16, 33, 63, 64, 65, 90]))
+    P = int(rng.choice([1, 2, 5, 16, 31, 62, 63, 64, 65, 90]))
+    L = int(K + 2 + rng.integers(0, 40))
+    steps = min(L - 1, 24)
+    ragged = bool(rng.integers(0, 2)) and T >= 4 and P >= 2
+    dtype = "fp32"
+    tag = f"case {case}: heads {heads} K {K} layers {layers} ffn {ffn} V {cb} B {B} T {T} P {P} L {L} steps {steps} ragged {ragged}"
+    try:
+        cfg = tiny_config(num_codebooks=K, hidden=64 * heads, layers=layers, heads=heads, ffn=ffn, codebook_size=cb, max_positions=256)
+        sd = synthetic_state_dict(cfg, seed=int(rng.integers(1, 1000)), never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+        got, want, ref_ids, got_raw = tg._oracle_vs_engine(cfg, sd, dtype, B=B, T=T, P=P, L=L, seed=int(rng.integers(1, 1000)), steps=steps,
+                                                           ragged=ragged)
+        err = float((got - want).abs().max())
+        top2 = torch.topk(want, 2, dim=-1)[0]
+        safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+        same = bool(torch.equal(got.argmax(-1)[safe], want.argmax(-1)[safe]))
+        ok = err < 2e-4 and same and bool(torch.isfinite(got).all())
+        print(f"{'ok  ' if ok else 'FAIL'} {tag}: max |dlogit| {err:.2e}, clear argmaxes equal {same}", flush=True)
+        fails += 0 if ok else 1
+    except Exception as e:      # a refused shape must be a clean error, never a fault
+        fails += 1
+        print(f"EXC  {tag}: {type(e).__name__}: {e}", flush=True)
+        traceback.print_exc()
+print(f"{n_cases - fails} of {n_cases} cases passed")
+sys.exit(1 if fails else 0)
