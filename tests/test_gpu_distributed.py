@@ -19,3 +19,15 @@ def test_every_collective_of_the_dp_path_runs_on_rccl_world_size_1():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_rccl_child.py")], capture_output=True, text=True, env=env,
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["12", "7"], ["8", "7", "generate"]], ids=["teacher_forced", "generate_api"])
+def test_randomised_parity_sweep(args):
+    """tools/fuzz_parity.py in a child process: random tiny architectures and call shapes the fixtures do not cover (codebooks 1 .. 32,
+    batch 1 .. 40, prompts across the 64-token KV page, ragged masks; with `generate`: the public call, free-running, live EOS heads,
+    guidance) - fp32 engine vs the oracle.  A fixed seed: the same cases on every run."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on an MI355X box")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")] + args, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
