@@ -22,7 +22,7 @@ def test_every_collective_of_the_dp_path_runs_on_rccl_world_size_1():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [["12", "7"], ["8", "7", "generate"]], ids=["teacher_forced", "generate_api"])
+@pytest.mark.parametrize("args", [["12", "7"], ["8", "7", "generate"], ["10", "7", "bf16"]], ids=["teacher_forced", "generate_api", "bf16"])
 def test_randomised_parity_sweep(args):
     """tools/fuzz_parity.py in a child process: random tiny architectures and call shapes the fixtures do not cover (codebooks 1 .. 32,
     batch 1 .. 40, prompts across the 64-token KV page, ragged masks; with `generate`: the public call, free-running, live EOS heads,
