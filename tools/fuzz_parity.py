@@ -56,10 +56,31 @@ def generate_case(case):
             amask[b, T - (7 * b) % (T // 2):] = 0
             pmask[b, : (5 * b) % (P // 2 + 1)] = 0
     kw = dict(guidance_scale=gs) if gs > 1 else {}
+    okw, extra = {}, ""
+    # call shapes beside the plain one: a decoder prefix (M:2150-2195), with a decoder_attention_mask over it when the call carries a
+    # prompt mask (M:845-846), or the prompt handed in pre-embedded (prompt_hidden_states, M:2476)
+    variant = int(rng.integers(0, 4))
+    if variant == 1 and L > K + 8:
+        s_pre = int(rng.integers(1, 6))
+        prefix = torch.randint(0, cfg.decoder.pad_token_id, (B * K, s_pre), generator=g)
+        okw["decoder_input_ids"] = prefix
+        extra = f" prefix {s_pre}"
+        if ragged and s_pre >= 2:
+            dmask = torch.ones(B, s_pre, dtype=torch.long)
+            dmask[B - 1, : s_pre // 2] = 0
+            prefix.reshape(B, K, s_pre)[B - 1, :, : s_pre // 2] = cfg.decoder.pad_token_id
+            okw["decoder_attention_mask"] = dmask
+            extra += " masked"
+    elif variant == 2:
+        okw["prompt_hidden_states"] = torch.nn.functional.embedding(prompt, sd["embed_prompts.weight"])
+        extra = " pre-embedded prompt"
+    tag += extra
     enc = cpu_ref.t5_encode(cfg, sd, desc, amask)
-    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, pmask, L, **kw)
+    ref = cpu_ref.generate_ids(cfg, sd, enc, amask, None if "prompt_hidden_states" in okw else prompt, pmask, L, **kw, **okw)
     model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device="cuda:0")
-    gk = dict(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L, return_raw_ids=True, **kw)
+    gk = dict(input_ids=desc, attention_mask=amask, do_sample=False, max_length=L, return_raw_ids=True, **kw, **okw)
+    if "prompt_hidden_states" not in okw:
+        gk["prompt_input_ids"] = prompt
     if pmask is not None:
         gk["prompt_attention_mask"] = pmask
     model.generate(**gk)
@@ -73,8 +94,13 @@ def generate_case(case):
         if len(diff) == 0:
             continue
         c = int(diff[0])
-        # the decision that filled column c: step c - 1; benign if the oracle's own gap on a differing row is tiny
-        m = float(margins[c - 1][rows][(got[rows, c] != want[rows, c])].min())
+        # the decision that filled column c: step c - c0 (c0 = columns present before the first step: 1, or 1 + the prefix);
+        # benign if the oracle's own gap on a differing row is tiny
+        c0 = want.shape[1] - margins.shape[0]
+        if c < c0:
+            bad = (b, c, float("inf"))
+            continue
+        m = float(margins[c - c0][rows][(got[rows, c] != want[rows, c])].min())
         if m < 1e-3:
             benign += 1
         else:
