@@ -1522,7 +1522,10 @@ int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, 
         size_t T = F; int ch = c.dac_hidden;
         for (int i = 0; i < c.dac_n_up; ++i) { T *= c.dac_up[i]; ch /= 2; if (T * ch > per_utt) per_utt = T * ch; }
     }
-    const size_t budget = (size_t)12 << 30;   // bytes per ping-pong buffer
+    // bytes per ping-pong buffer (two of them): 12 GiB cuts a batch of 32 benchmark clips (0.5 GB per utterance at the widest layer)
+    // into 23 + 9; PTTS_DAC_WORKSPACE_GB raises or lowers it (288 GB of HBM: 17 GiB takes the 32 in one piece)
+    size_t budget = (size_t)12 << 30;
+    if (const char* v = getenv("PTTS_DAC_WORKSPACE_GB")) { const long g = atol(v); if (g >= 1 && g <= 96) budget = (size_t)g << 30; }
     int chunk = (int)(budget / (per_utt * sizeof(float)));
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
