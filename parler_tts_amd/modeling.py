@@ -298,6 +298,27 @@ def _hipMemcpyDtoD(dst: int, src: int, nbytes: int) -> int:
     return _hiprt.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), nbytes, 3)  # hipMemcpyDeviceToDevice
 
 
+def _warp_scores(scores: torch.Tensor, gen) -> torch.Tensor:
+    """What the third-party `sample` loop stores as a step's scores: the processed scores after its warpers, in their order -
+    TemperatureLogitsWarper, TopKLogitsWarper (threshold = the k-th largest value, ties kept), TopPLogitsWarper (ascending
+    cumulative probability <= 1 - top_p removed, at least one token kept).  Host-side copy of what select_kernel applies on the
+    device; only used to REPORT scores (`output_scores=True`), never to choose a token."""
+    s = scores.float()
+    if gen.temperature is not None and float(gen.temperature) != 1.0:
+        s = s / float(gen.temperature)
+    if gen.top_k is not None and int(gen.top_k) > 0:
+        k = min(int(gen.top_k), s.shape[-1])
+        thr = torch.topk(s, k)[0][..., -1, None]
+        s = s.masked_fill(s < thr, -float("inf"))
+    if gen.top_p is not None and float(gen.top_p) < 1.0:
+        srt, idx = torch.sort(s, descending=False)
+        cum = srt.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1 - float(gen.top_p))
+        remove[..., -1:] = False
+        s = s.masked_fill(remove.scatter(1, idx, remove), -float("inf"))
+    return s
+
+
 class DACModel:
     """Codec wrapper with the reference's ``decode`` contract (dac_wrapper/modeling_dac.py:98-134):
     ``audio_codes [1, B, K, F]`` -> ``audio_values [B, 1, F * hop]``.  The arithmetic (quantizer.from_codes +
@@ -705,7 +726,12 @@ class ParlerTTSForConditionalGeneration:
         # ---- the hot loop: state lives on the device, the host only polls for "all rows finished" ----
         remaining = L - start_len
         L_out = L
-        if logits_processor or stopping_criteria:
+        # `output_scores=True` with `return_dict_in_generate=True` (third-party loop, reached from M:2582 / M:2608): the processed
+        # scores of every step come back as a tuple of [batch * codebooks, vocab] tensors - after the guidance combine, the
+        # default / user processors and, under sampling, the warpers.  They exist on the host only in the step-wise form below.
+        collect_scores = bool(gen.output_scores and gen.return_dict_in_generate)
+        step_scores = []
+        if logits_processor or stopping_criteria or collect_scores:
             # custom processors / criteria are host callables (M:2561-2573): one step at a time, the scores pass through
             # them between the forward half and the selection half, in the order of the third-party loop
             # (processors on [B*K, vocab] scores after the guidance combine, then the warpers inside the select kernel)
@@ -718,8 +744,15 @@ class ParlerTTSForConditionalGeneration:
                 if use_cfg:
                     scores = scores[n:] + (scores[:n] - scores[n:]) * float(gen.guidance_scale)      # M:2556-2558
                 seen = raw_ids[:, :cur]
+                if collect_scores and eos_free_until and cur < eos_free_until:
+                    # MinLength / MinNewTokensLength sit in FRONT of the user's processors in the merged list; the select kernel
+                    # masks EOS again below the bound (idempotent), here the reported scores get what those processors write
+                    scores = scores.clone()
+                    scores[:, gen.eos_token_id] = -float("inf")
                 for proc in logits_processor:
                     scores = proc(seen, scores)
+                if collect_scores:
+                    step_scores.append(_warp_scores(scores, gen) if sample else scores.clone())
                 eng.set_logits(torch.cat([scores, scores], dim=0) if use_cfg else scores)
                 eng.select_step(sp)
                 remaining -= 1
@@ -803,9 +836,9 @@ class ParlerTTSForConditionalGeneration:
         if gen.return_dict_in_generate:
             # M:2682-2684: the third-party loop's own output object with `.sequences` overwritten by the waveform.  That object
             # is a Greedy/SampleEncoderDecoderOutput (transformers 4.3x): its other fields are None unless `output_scores` /
-            # `output_attentions` / `output_hidden_states` were asked for; this engine keeps no per-step scores, so they stay None
-            return ModelOutput(sequences=values, scores=None, encoder_attentions=None, encoder_hidden_states=None,
-                               decoder_attentions=None, cross_attentions=None, decoder_hidden_states=None)
+            # `output_attentions` / `output_hidden_states` were asked for; `scores` is served (above), attentions / hidden states never leave the kernels
+            return ModelOutput(sequences=values, scores=tuple(step_scores) if collect_scores else None, encoder_attentions=None,
+                               encoder_hidden_states=None, decoder_attentions=None, cross_attentions=None, decoder_hidden_states=None)
         return values
 
 

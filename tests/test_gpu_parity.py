@@ -2059,6 +2059,46 @@ def test_custom_logits_processors_and_stopping_criteria(hip):
     assert short.shape[-1] < base.shape[-1] or base.shape[-1] == 0
 
 
+def test_output_scores_with_return_dict_in_generate(hip):
+    """`generate(output_scores=True, return_dict_in_generate=True)` (third-party loop behind M:2582 / M:2608): one [batch * codebooks,
+    vocab] tensor of PROCESSED scores per step.  Greedy: every step's scores equal the reference fixture's logits (2e-4) and their
+    argmax are the ids of the run; with `min_length` the EOS column is -inf below the bound.  Sampling: step 0's scores are the
+    reference logits after temperature / top-k (the -inf pattern exactly, finite entries 2e-4); later steps follow the engine's own
+    Philox draws, so only their shape and top-k count are checked."""
+    f, meta = load_case("tiny_greedy")
+    cfg, model = model_for("tiny_greedy", meta, "fp32")
+    desc, amask, prompt, _ = case_inputs(f)
+    L, K = int(f["max_length"]), cfg.decoder.num_codebooks
+    kw = dict(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, max_length=L, return_dict_in_generate=True)
+    out = model.generate(**kw, do_sample=False, output_scores=True)
+    assert isinstance(out.scores, tuple) and len(out.scores) == L - 1 and out.sequences.dim() == 2
+    got = torch.stack([x.cpu() for x in out.scores])
+    assert got.shape == f["step_logits"].shape and np.abs(got.numpy() - f["step_logits"]).max() < 2e-4
+    assert np.array_equal(model.last_codes[0].cpu().numpy(), f["codes"])
+    free = free_positions(f["pattern"], L - 1)
+    assert np.array_equal(got.argmax(-1).numpy()[free], f["raw_ids"][:, 1:].T[free])
+    assert model.generate(**kw, do_sample=False).scores is None                              # not asked for: None, the fast path
+    eos = cfg.decoder.eos_token_id
+    out = model.generate(**kw, do_sample=False, output_scores=True, min_length=8)
+    col = torch.stack([x.cpu() for x in out.scores])[:, :, eos]
+    assert bool(torch.isinf(col[:7]).all()) and bool(torch.isfinite(col[7:]).all())     # columns 1 .. 7 filled below the bound
+    # sampling: the fixture's step-0 logits through the warpers
+    g, gmeta = load_case("tiny_sample")
+    cfg2, model2 = model_for("tiny_sample", gmeta, "fp32")
+    d2, a2, p2, _ = case_inputs(g)
+    out = model2.generate(input_ids=d2, attention_mask=a2, prompt_input_ids=p2, max_length=int(g["max_length"]), do_sample=True,
+                          temperature=0.7, top_k=50, seed=5, return_dict_in_generate=True, output_scores=True)
+    s0 = out.scores[0].cpu()
+    ref = torch.from_numpy(g["step_logits"][0]) / 0.7
+    thr = torch.topk(ref, 50)[0][..., -1, None]
+    keep = ref >= thr
+    clear = (ref - thr).abs() > 1e-3                      # an entry within 1e-3 of the threshold may fall on either side
+    assert torch.equal(torch.isfinite(s0)[clear], keep[clear])
+    both = keep & torch.isfinite(s0)
+    assert (s0[both] - ref[both]).abs().max() < 3e-4
+    assert all(tuple(x.shape) == tuple(s0.shape) and int(torch.isfinite(x).sum(-1).min()) >= 50 for x in out.scores)
+
+
 def test_lookahead_cross_q_agrees_with_separate_projection(hip):
     """Look-ahead cross-q (x.Wq' + a.(Wq'.Wo) inside the out-projection launch, LayerNorm applied by the cross-attention
     kernel from per-block statistics) vs the separate folded projection: same model, same teacher-forced tokens."""
