@@ -448,13 +448,40 @@ class ParlerTTSForConditionalGeneration:
     def from_synthetic(cls, config: ParlerTTSConfig, seed: int = 0, dtype: str = "bf16", device="cuda:0", **sd_kw):
         return cls(config, synthetic_state_dict(config, seed=seed, **sd_kw), dtype=dtype, device=device)
 
-    def to(self, device):
-        dev = torch.device(device)
-        if dev.type != "cuda":
-            raise RuntimeError("this engine only runs on an MI355X (device type 'cuda' under ROCm)")
-        if dev != self.device:
-            self.device, self._engine, self._dac = dev, None, None
+    def to(self, *args, **kwargs):
+        """`nn.Module.to` as inference users call it: a device, a dtype (`torch.bfloat16` = the bf16 engine mode, `torch.float32` = the
+        bit-exact fp32 mode; half precision is not an engine mode), or both.  A change drops the engine: it is rebuilt (weights
+        re-tiled in the new dtype / on the new device) at the next call."""
+        device, dtype = kwargs.get("device"), kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif a is not None:
+                device = a
+        if dtype is not None:
+            names = {torch.bfloat16: "bf16", torch.float32: "fp32"}
+            if dtype not in names:
+                raise NotImplementedError(f"{dtype}: the engine computes in bfloat16 or float32")
+            if names[dtype] != self.dtype:
+                if self._engine is not None:
+                    self._engine.close()
+                self.dtype, self._engine, self._dac = names[dtype], None, None
+        if device is not None:
+            dev = torch.device(device)
+            if dev.type != "cuda":
+                raise RuntimeError("this engine only runs on an MI355X (device type 'cuda' under ROCm)")
+            if dev != self.device:
+                self.device, self._engine, self._dac = dev, None, None
         return self
+
+    def bfloat16(self):
+        return self.to(torch.bfloat16)
+
+    def float(self):
+        return self.to(torch.float32)
+
+    def half(self):
+        return self.to(torch.float16)          # raises: not an engine mode
 
     def eval(self):
         return self
@@ -892,8 +919,8 @@ class ParlerTTSForCausalLM:
         self.generation_config = self._inner.generation_config
         self.device = self._inner.device
 
-    def to(self, device):
-        self._inner.to(device)
+    def to(self, *args, **kwargs):
+        self._inner.to(*args, **kwargs)
         self.device = self._inner.device
         return self
 

@@ -2059,6 +2059,31 @@ def test_custom_logits_processors_and_stopping_criteria(hip):
     assert short.shape[-1] < base.shape[-1] or base.shape[-1] == 0
 
 
+def test_model_to_dtype_switches_the_engine_mode(hip):
+    """`model.to(torch.bfloat16)` / `.float()` as a reference user writes them: the engine is rebuilt in the other mode; back in
+    float32 the ids are the reference's again, bit for bit; float16 is refused."""
+    f, meta = load_case("tiny_greedy")
+    cfg, sd = state_dict_for("tiny_greedy", meta, parts=("text_encoder", "decoder", "audio_encoder"))
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device="cuda:0")
+    desc, amask, prompt, _ = case_inputs(f)
+    kw = dict(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=int(f["max_length"]))
+    model.generate(**kw)
+    assert np.array_equal(model.last_codes[0].cpu().numpy(), f["codes"])
+    assert model.to(torch.bfloat16) is model and model.dtype == "bf16"
+    wav16 = model.generate(**kw)
+    assert wav16.shape[0] == desc.shape[0] and bool(torch.isfinite(wav16).all())
+    assert (model.last_codes[0].cpu().numpy() == f["codes"]).mean() > 0.8          # bf16: close, not bit-exact
+    model.to("cuda:0", torch.float32)
+    model.generate(**kw)
+    assert model.dtype == "fp32" and np.array_equal(model.last_codes[0].cpu().numpy(), f["codes"])
+    with pytest.raises(NotImplementedError):
+        model.half()
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_output_scores_with_return_dict_in_generate(hip):
     """`generate(output_scores=True, return_dict_in_generate=True)` (third-party loop behind M:2582 / M:2608): one [batch * codebooks,
     vocab] tensor of PROCESSED scores per step.  Greedy: every step's scores equal the reference fixture's logits (2e-4) and their
