@@ -424,6 +424,12 @@ class ParlerTTSForConditionalGeneration:
         """Local checkpoint directory in the reference layout (config.json + safetensors), M:1701-1720."""
         if not os.path.isdir(path):
             raise OSError(f"{path} is not a local directory (hub downloads are not available here)")
+        td = kw.pop("torch_dtype", None)          # the transformers spelling: torch.bfloat16 / torch.float32 (or their names)
+        if td is not None:
+            names = {torch.bfloat16: "bf16", torch.float32: "fp32", "bfloat16": "bf16", "float32": "fp32", "bf16": "bf16", "fp32": "fp32"}
+            if td not in names:
+                raise NotImplementedError(f"torch_dtype={td}: the engine computes in bfloat16 or float32")
+            dtype = names[td]
         cfg = ParlerTTSConfig.from_pretrained(path)
         sd = normalize_state_dict(load_state_dict_from_dir(path), cfg)
         gen = None

@@ -1512,7 +1512,7 @@ def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
     # model.save_pretrained(): the loaded (normalised) state dict written back and read again gives the same codes
     again = tmp_path / "again"
     model.save_pretrained(str(again))
-    model2 = ParlerTTSForConditionalGeneration.from_pretrained(str(again), dtype="fp32")
+    model2 = ParlerTTSForConditionalGeneration.from_pretrained(str(again), torch_dtype=torch.float32)     # the transformers spelling
     assert model2.generation_config.max_length == 24
     model2.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt)
     assert np.array_equal(model2.last_codes[0].cpu().numpy(), f["codes"])
