@@ -570,7 +570,7 @@ def main():
                 "algorithmic_bytes_per_step": int(chain_bytes), "ms_per_step": round(chain_ms, 4),
                 "launches_per_step": 6 * L_ + 4,
                 "derived": "decode loop ms per step (graph replay) minus layers x the sampled self-attention launch average",
-                "counters": "profiles/r03_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
+                "counters": "profiles/r04_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
         if dp is not None:
             line["data_parallel"] = dp
         if plumbing:
