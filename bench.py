@@ -241,7 +241,7 @@ def dp_report(dist, world, coll_dev, phase, timings, steps, value, root=ROOT):
            "slowest_rank_by_decode": int(m[:, 1].argmax())}
     n1, src = None, None
     import glob
-    for path in sorted(glob.glob(os.path.join(root, "BENCH_r*.json")), reverse=True) + [os.path.join(root, "profiles", "r03_bench_default.json")]:
+    for path in sorted(glob.glob(os.path.join(root, "BENCH_r*.json")), reverse=True) + [os.path.join(root, "profiles", "r04_bench_default.json")]:
         try:
             rec = json.load(open(path))
             rec = rec.get("parsed", rec)
