@@ -12,8 +12,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 constexpr int NW = 8, WT = 4, AT = 8;
 
+// `spin` > 0: a dependent integer chain of that many steps behind the loads (stands for the ~1.7 us of MFMAs, K-split hand-over and
+// epilogue a product launch spends after its bytes have landed: the window in which a prefetch for the next launch could travel)
+__device__ inline unsigned tail_work(unsigned r, int spin) {
+    for (int i = 0; i < spin; ++i) r = r * 1664525u + 1013904223u;
+    return r;
+}
+
 template <bool DMA>
-__global__ __launch_bounds__(512) void k(const u32x4* __restrict__ w, const u32x4* __restrict__ a, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(512) void k(const u32x4* __restrict__ w, const u32x4* __restrict__ a, unsigned* __restrict__ out, int spin = 0) {
     __shared__ u32x4 lds[NW * (WT + AT) * 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32x4* wp = w + ((size_t)blockIdx.x * NW + wv) * WT * 64 + lane;
@@ -42,9 +49,35 @@ __global__ __launch_bounds__(512) void k(const u32x4* __restrict__ w, const u32x
 #pragma unroll
         for (int t = 0; t < WT; ++t) acc ^= vw[t];
     }
-    const unsigned r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    const unsigned r = tail_work(acc.x ^ acc.y ^ acc.z ^ acc.w, spin);
     if (r == 0x12345678u) out[blockIdx.x * 512 + tid] = r;
     if (tid == 0) out[blockIdx.x] = r;         // one word: the next launch depends on nothing but the boundary
+}
+
+// Variant P: as the VGPR-load kernel, plus - right behind its own loads - a SPARSE touch (4 bytes per 128-byte line) of the NEXT launch's
+// weights: workgroup j touches the 32 KB that workgroup j of the next launch will read (same blockIdx % 8 = the same XCD's L2 under
+// round-robin placement), i.e. 256 lines = 4 wave-instructions per workgroup.  The lines travel HBM -> L2 while this launch multiplies.
+__global__ __launch_bounds__(512) void k_pf(const u32x4* __restrict__ w, const u32x4* __restrict__ a, const unsigned* __restrict__ wnext,
+                                             unsigned* __restrict__ out, int spin) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32x4* wp = w + ((size_t)blockIdx.x * NW + wv) * WT * 64 + lane;
+    const u32x4* ap = a + (size_t)wv * AT * 64 + lane;
+    u32x4 acc = {0, 0, 0, 0};
+    u32x4 va[AT], vw[WT];
+#pragma unroll
+    for (int t = 0; t < AT; ++t) va[t] = ap[t * 64];
+#pragma unroll
+    for (int t = 0; t < WT; ++t) vw[t] = __builtin_nontemporal_load(wp + t * 64);
+    unsigned pf = 0;
+    if (wv < 4)      // 4 waves x 64 lanes x one dword per 128-byte line = the next launch's 32 KB for this block id
+        pf = wnext[((size_t)blockIdx.x * NW * WT * 1024 + (size_t)(wv * 64 + lane) * 128) / 4];
+#pragma unroll
+    for (int t = 0; t < AT; ++t) acc ^= va[t];
+#pragma unroll
+    for (int t = 0; t < WT; ++t) acc ^= vw[t];
+    const unsigned r = tail_work(acc.x ^ acc.y ^ acc.z ^ acc.w, spin) ^ pf;      // the prefetched words are needed only at the very end
+    if (r == 0x12345678u) out[blockIdx.x * 512 + tid] = r;
+    if (tid == 0) out[blockIdx.x] = r;
 }
 
 template <typename F> double run(hipStream_t s, int n, int reps, F launch) {
@@ -73,9 +106,26 @@ int main() {
     CK(hipMemset(w, 0, wbytes * NB)); CK(hipMemset(a, 0, (size_t)NW * AT * 1024));
     const int n = 192, reps = 40;
     for (int round = 0; round < 3; ++round) {
-        const double tv = run(s, n, reps, [&](hipStream_t q, int i) { hipLaunchKernelGGL(k<false>, dim3(WG), dim3(512), 0, q, w + (size_t)(i % NB) * (wbytes / 16), a, out); });
-        const double td = run(s, n, reps, [&](hipStream_t q, int i) { hipLaunchKernelGGL(k<true>, dim3(WG), dim3(512), 0, q, w + (size_t)(i % NB) * (wbytes / 16), a, out); });
+        const double tv = run(s, n, reps, [&](hipStream_t q, int i) { hipLaunchKernelGGL(k<false>, dim3(WG), dim3(512), 0, q, w + (size_t)(i % NB) * (wbytes / 16), a, out, 0); });
+        const double td = run(s, n, reps, [&](hipStream_t q, int i) { hipLaunchKernelGGL(k<true>, dim3(WG), dim3(512), 0, q, w + (size_t)(i % NB) * (wbytes / 16), a, out, 0); });
         printf("round %d: 96 KB per workgroup (32 KB HBM + 64 KB L2) - VGPR loads %.3f us/launch | LDS-DMA + ds_read %.3f us/launch\n", round, tv, td);
+        // the same with the weights cache-resident (one 8 MB buffer every launch: each XCD's L2 keeps its eighth): what a launch would
+        // gain if something had pulled its weights in ahead of it
+        const double tr = run(s, n, reps, [&](hipStream_t q, int i) { hipLaunchKernelGGL(k<false>, dim3(WG), dim3(512), 0, q, w, a, out, 0); });
+        printf("         weights cache-resident (same 8 MB every launch) - VGPR loads %.3f us/launch\n", tr);
+        const double tp = run(s, n, reps, [&](hipStream_t q, int i) {
+            hipLaunchKernelGGL(k_pf, dim3(WG), dim3(512), 0, q, w + (size_t)(i % NB) * (wbytes / 16), a,
+                               (const unsigned*)(w + (size_t)((i + 1) % NB) * (wbytes / 16)), out, 0); });
+        printf("         rotating weights, each launch sparse-touches the NEXT launch's 32 KB per workgroup - %.3f us/launch\n", tp);
+        for (int spin : {400, 800}) {
+            const double c = run(s, n, reps, [&](hipStream_t q, int i) { hipLaunchKernelGGL(k<false>, dim3(WG), dim3(512), 0, q, w + (size_t)(i % NB) * (wbytes / 16), a, out, spin); });
+            const double h = run(s, n, reps, [&](hipStream_t q, int i) { hipLaunchKernelGGL(k<false>, dim3(WG), dim3(512), 0, q, w, a, out, spin); });
+            const double f = run(s, n, reps, [&](hipStream_t q, int i) {
+                hipLaunchKernelGGL(k_pf, dim3(WG), dim3(512), 0, q, w + (size_t)(i % NB) * (wbytes / 16), a,
+                                   (const unsigned*)(w + (size_t)((i + 1) % NB) * (wbytes / 16)), out, spin); });
+            printf("         with a %d-step dependent tail behind the loads: cold weights %.3f | resident %.3f | cold + prefetch of the next launch's %.3f us/launch\n",
+                   spin, c, h, f);
+        }
     }
     return 0;
 }
