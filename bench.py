@@ -279,6 +279,8 @@ class _PlumbingModel:
         K = self.cfg.decoder.num_codebooks
         base = (input_ids.sum(dim=1) + prompt_input_ids.sum(dim=1)).view(-1, 1, 1)
         self.last_codes = ((base + torch.arange(K).view(1, K, 1) + 5 * torch.arange(max_length - K).view(1, 1, -1)) % 1024)[None]
+        if os.environ.get("PTTS_PLUMBING_CORRUPT_RANK") == os.environ.get("RANK", "0"):
+            self.last_codes = (self.last_codes + 1) % 1024     # test hook: this rank computes something else than rank 0 would
         if self.phase_times is not None:
             self.phase_times["decode_ms"] += 1.0
         return None
@@ -324,43 +326,233 @@ def launch_ranks(args, argv):
     return rc
 
 
+def reference_audit(dev, name="minilong2580_greedy"):
+    """What "bit-exact token ids" means, in numbers, on THIS box.  `tests/golden/<name>.npz` holds a run of
+    the REAL reference (fp32, CPU) at the mini_v0.1 shape over the benchmark's full horizon (B = 2, 2579 steps; written in the
+    build container by oracle/gen_golden.py from the imported reference: raw ids and the top-2 margin of EVERY argmax).  The fp32
+    engine runs the same inputs through the public generate(), nothing forced, and its ids are compared column by column.  The
+    fixture is data (arrays), not reference code; /root/reference is not read."""
+    import numpy as np
+
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    f = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    meta = json.loads(str(f["meta"]))
+    cfg = mini_v01_config()
+    sd = synthetic_state_dict(cfg, parts=("decoder",), **meta["sd_kw"])
+    K, L = cfg.decoder.num_codebooks, int(f["max_length"])
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device=dev)
+    try:
+        t0 = time.perf_counter()
+        model.generate(encoder_outputs=(torch.from_numpy(f["enc_t5"]),), attention_mask=torch.from_numpy(f["amask"]),
+                       prompt_input_ids=torch.from_numpy(f["prompt"]),
+                       prompt_attention_mask=torch.from_numpy(f["pmask"]) if int(f["has_pmask"]) else None,
+                       do_sample=False, max_length=L, return_raw_ids=True)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        got = model.last_raw_ids.cpu().numpy()
+    finally:
+        if model._engine is not None:
+            model._engine.close()
+    gold, margins = f["raw_ids"], f["margins"]                    # [rows, L], [steps, rows]
+    free = (f["pattern"][:, 1:L] == -1)                           # [rows, steps]: the token of step j (column j + 1) is kept
+    diff = (got[:, 1:] != gold[:, 1:]) & free
+    B = gold.shape[0] // K
+    first, first_margin = [], []
+    for b in range(B):
+        rows = slice(b * K, (b + 1) * K)
+        cols = np.nonzero(diff[rows].any(0))[0]
+        if len(cols) == 0:
+            first.append(None)
+            first_margin.append(None)
+        else:
+            c = int(cols[0])
+            first.append(c)
+            first_margin.append(float(margins[c][rows][diff[rows][:, c]].max()))
+    kept = int(free.sum())
+    below = int((free & (margins.T < 5e-4)).sum())
+    worst = max([m for m in first_margin if m is not None], default=None)
+    if all(c is None for c in first):
+        text = f"fp32 engine, free-running: ids equal to the reference's at all {kept} kept argmaxes of {name}"
+    else:
+        text = (f"fp32 engine, free-running on {name}: ids equal to the reference's up to the first step the reference itself decides by "
+                f"< 5e-4 (first differing step per utterance {first}, reference top-2 margin there {['%.1e' % m if m is not None else None for m in first_margin]}); "
+                f"{int(kept - diff.sum())} of {kept} kept argmaxes equal over the whole run")
+    return {"fixture": f"tests/golden/{name}.npz (the real reference's run, fp32 CPU, B={B}, {L - 1} steps, mini_v0.1 shape)",
+            "kept_argmaxes": kept, "reference_margin_below_5e-4": below, "ids_equal": int(kept - diff.sum()),
+            "first_differing_step_per_utterance": first, "reference_margin_at_first_difference": first_margin,
+            "consistent_with_bit_exact_up_to_reference_margin_5e-4": worst is None or worst < 5e-4,
+            "statement": text, "seconds": round(dt, 2),
+            "tests": "tests/test_gpu_parity.py::test_fp32_free_running_audit_against_the_fp32_reference_ids (this check), "
+                     "::test_fp32_long_horizon_against_the_reference (teacher-forced: logits < 2e-4 at the sampled steps, own argmax equal "
+                     "wherever the reference margin is >= 5e-4, the rest counted)"}
+
+
 def fp32_parity_pass(cfg, sd, dev, desc, amask, prompt, B, T, P, L, bf16_codes):
-    """north_star asks for bit-exact token ids; those hold in the engine's fp32 parity mode (tests/test_gpu_parity.py:
-    ids equal to the reference's over 2579 steps at this very shape), while `value` is measured in bf16.  What the bit-exact
-    mode costs: ONE timed full generate() pass in fp32 on the same inputs (engine built and a 40-column pass run untimed
-    first: allocation, weight re-tiling, graph capture), plus how far the bf16 pass's codec ids are from the fp32 ones."""
+    """north_star asks for bit-exact token ids; those are claimed in the engine's fp32 parity mode, while `value` is measured in
+    bf16.  What that mode costs: ONE timed full generate() pass in fp32 on the same inputs (engine built and a 40-column pass run
+    untimed first: allocation, weight re-tiling, graph capture), how far the bf16 pass's codec ids are from the fp32 ones, and -
+    `reference_audit` - how the fp32 ids compare with a run of the real reference at this shape and horizon."""
     from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
 
     K = cfg.decoder.num_codebooks
     m32 = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device=dev)
-    m32.audio_encoder
-    m32.engine(B, T, P, L)
-    m32.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=40)
-    torch.cuda.synchronize(dev)
-    phase = {"t5_prefill_ms": 0.0, "decode_ms": 0.0, "post_ms": 0.0}
-    m32.phase_times = phase
-    t0 = time.perf_counter()
-    m32.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    n_steps = L - 1
-    out = {"dtype": "fp32", "passes": 1, "tokens_per_s": round(B * K * n_steps / dt, 1), "ms_per_pass": round(dt * 1e3, 2),
-           "decode_ms_per_step": round(phase["decode_ms"] / n_steps, 4),
-           "decode_loop_tokens_per_s": round(B * K * n_steps / (phase["decode_ms"] / 1e3), 1),
-           "phase_ms": {k: round(v, 2) for k, v in phase.items()},
-           "decode_loop_roofline": decode_loop_roofline(cfg.decoder, B, T, P, n_steps, 4, phase["decode_ms"] / 1e3),
-           "parity": "ids bit-exact vs the reference in this mode: tests/test_gpu_parity.py::test_fp32_long_horizon_against_the_reference"}
-    if bf16_codes is not None:
-        c32, c16 = m32.last_codes[0], bf16_codes[0]
-        same = (c32 == c16)
-        cols = same.all(dim=1)                               # [B, F]: every codebook of the frame equal
-        first = [int((~cols[b]).nonzero()[0]) if not bool(cols[b].all()) else int(cols.shape[1]) for b in range(cols.shape[0])]
-        out["bf16_run_vs_this_run"] = {"ids_equal_frac": round(float(same.float().mean()), 4),
-                                       "first_differing_frame_min_median_max": [min(first), sorted(first)[len(first) // 2], max(first)],
-                                       "frames": int(cols.shape[1]),
-                                       "note": "free-running greedy: after the first flipped argmax a row follows another path"}
-    m32._engine.close()
+    try:
+        m32.audio_encoder
+        m32.engine(B, T, P, L)
+        m32.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=40)
+        torch.cuda.synchronize(dev)
+        phase = {"t5_prefill_ms": 0.0, "decode_ms": 0.0, "post_ms": 0.0}
+        m32.phase_times = phase
+        t0 = time.perf_counter()
+        m32.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        n_steps = L - 1
+        out = {"dtype": "fp32", "passes": 1, "tokens_per_s": round(B * K * n_steps / dt, 1), "ms_per_pass": round(dt * 1e3, 2),
+               "decode_ms_per_step": round(phase["decode_ms"] / n_steps, 4),
+               "decode_loop_tokens_per_s": round(B * K * n_steps / (phase["decode_ms"] / 1e3), 1),
+               "phase_ms": {k: round(v, 2) for k, v in phase.items()},
+               "decode_loop_roofline": decode_loop_roofline(cfg.decoder, B, T, P, n_steps, 4, phase["decode_ms"] / 1e3)}
+        if bf16_codes is not None:
+            c32, c16 = m32.last_codes[0], bf16_codes[0].to(m32.last_codes.device)
+            same = (c32 == c16)
+            cols = same.all(dim=1)                               # [B, F]: every codebook of the frame equal
+            first = [int((~cols[b]).nonzero()[0]) if not bool(cols[b].all()) else int(cols.shape[1]) for b in range(cols.shape[0])]
+            out["bf16_run_vs_this_run"] = {"ids_equal_frac": round(float(same.float().mean()), 4),
+                                           "first_differing_frame_min_median_max": [min(first), sorted(first)[len(first) // 2], max(first)],
+                                           "frames": int(cols.shape[1]),
+                                           "note": "free-running greedy: after the first flipped argmax a row follows another path"}
+    finally:
+        if m32._engine is not None:
+            m32._engine.close()
+        m32._engine = None
+    try:
+        out["reference_audit"] = reference_audit(dev)
+        out["parity"] = out["reference_audit"]["statement"]
+    except Exception as e:
+        out["reference_audit"] = {"error": f"{type(e).__name__}: {e}"}
+        out["parity"] = "reference audit did not run on this box; see tests/test_gpu_parity.py::test_fp32_free_running_audit_against_the_fp32_reference_ids"
     return out
+
+
+def sampling_pass(cfg, sd, dev, desc, amask, prompt, B, T, P, L, greedy_ms_per_step=None):
+    """BASELINE configs[3] on the record: `do_sample=True` is the reference's DEFAULT mode (generation config of
+    helpers/model_init_scripts/init_model_600M.py:61; the third-party `sample` loop called at M:2597-2620).  Two full generate()
+    passes at B per GPU with top_k = 50, temperature = 0.7 and a fixed Philox seed: the first timed, the second must reproduce its
+    codec ids bit for bit (on-device sampling: temperature -> radix top-k -> softmax -> Philox inverse CDF inside select_kernel)."""
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+
+    K = cfg.decoder.num_codebooks
+    m = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device=dev)
+    try:
+        m.audio_encoder
+        m.engine(B, T, P, L)
+        kw = dict(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt, do_sample=True, top_k=50, temperature=0.7, seed=20261005)
+        m.generate(**kw, max_length=40)
+        torch.cuda.synchronize(dev)
+        phase = {"t5_prefill_ms": 0.0, "decode_ms": 0.0, "post_ms": 0.0}
+        m.phase_times = phase
+        t0 = time.perf_counter()
+        m.generate(**kw, max_length=L)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        first = m.last_codes.clone()
+        m.phase_times = None
+        m.generate(**kw, max_length=L)
+        torch.cuda.synchronize(dev)
+        same = bool(torch.equal(first, m.last_codes))
+        m.generate(**{**kw, "seed": 7}, max_length=200)
+        other = not bool(torch.equal(first[..., :m.last_codes.shape[-1]], m.last_codes))
+        n_steps = L - 1
+        full = int(first.shape[-1]) == L - K                           # never-EOS heads: every row runs every step
+        out = {"config": f"BASELINE configs[3]: parler_tts_mini_v0.1 bf16, batch {B}, do_sample=True, top_k=50, temperature=0.7, "
+                         f"T={T} P={P} max_length={L}, full generate() incl. T5, prefill and DAC",
+               "tokens_per_s": round(B * K * n_steps / dt, 1), "ms_per_pass": round(dt * 1e3, 2),
+               "decode_ms_per_step": round(phase["decode_ms"] / n_steps, 4),
+               "decode_loop_tokens_per_s": round(B * K * n_steps / (phase["decode_ms"] / 1e3), 1),
+               "phase_ms": {k: round(v, 2) for k, v in phase.items()},
+               "ran_all_steps": full, "two_passes_same_seed_bit_identical": same, "another_seed_gives_other_ids": other,
+               "distinct_ids_in_codebook0_of_utterance0": int(first[0, 0, 0].unique().numel()),
+               "parity": "tolerance-based (sampling): tests/test_gpu_parity.py post-warper probabilities within 1e-5 (fp32) of the oracle, "
+                         "chi-square of draws, teacher-forced ids of the reference's own sampled run (tiny_sample*)"}
+        if greedy_ms_per_step:
+            out["decode_ms_per_step_over_greedy"] = round(out["decode_ms_per_step"] / greedy_ms_per_step, 4)
+    finally:
+        if m._engine is not None:
+            m._engine.close()
+        m._engine = None
+    return out
+
+
+def extras_child(args):
+    """``--extras DIR`` (started by the headline process as a CHILD, never exec'd): the optional records next to the headline - the
+    fp32 parity pass, the sampling pass, the CPU baseline - in a process of their own, so that a fault or hang in one of them
+    cannot cost the line already measured.  Reads DIR/request.json, prints ONE JSON object."""
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    req = json.load(open(os.path.join(args.extras, "request.json")))
+    B, T, P, L = req["B"], req["T"], req["P"], req["L"]
+    cfg = mini_v01_config()
+    sd = synthetic_state_dict(cfg, seed=1234, never_eos=True)
+    out = {}
+    gpu = [k for k in req["sections"] if k != "cpu_baseline"]
+    if gpu:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        desc, prompt = synth_inputs(cfg, B, T, P, seed=1234)
+        desc, prompt = desc.to(dev), prompt.to(dev)
+        amask = torch.ones(B, T, dtype=torch.long, device=dev)
+    if "fp32_parity_mode" in req["sections"]:
+        try:
+            codes = torch.load(os.path.join(args.extras, "bf16_codes.pt")) if os.path.exists(os.path.join(args.extras, "bf16_codes.pt")) else None
+            out["fp32_parity_mode"] = fp32_parity_pass(cfg, sd, dev, desc, amask, prompt, B, T, P, L, codes)
+        except Exception as e:
+            out["fp32_parity_mode"] = {"error": f"{type(e).__name__}: {e}"}
+        print("[bench extras] fp32 parity pass done", file=sys.stderr, flush=True)
+    if "sampling_mode" in req["sections"]:
+        try:
+            out["sampling_mode"] = sampling_pass(cfg, sd, dev, desc, amask, prompt, B, T, P, L, req.get("greedy_ms_per_step"))
+        except Exception as e:
+            out["sampling_mode"] = {"error": f"{type(e).__name__}: {e}"}
+        print("[bench extras] sampling pass done", file=sys.stderr, flush=True)
+    if "cpu_baseline" in req["sections"]:
+        sd_dec = {k: v for k, v in sd.items() if not k.startswith(("text_encoder.", "audio_encoder."))}
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd_dec, B, T, P, L, full_b1=req.get("cpu_full_b1", False))
+        except Exception as e:
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}", "kind": "port"}
+    print(json.dumps(out), flush=True)
+
+
+def run_extras(sections, B, T, P, L, bf16_codes, greedy_ms_per_step, cpu_full_b1, timeout_s=1500):
+    """start the child, hand it the request, return its JSON object (or an `error` entry per section)"""
+    import shutil
+    import subprocess
+    import tempfile
+
+    d = tempfile.mkdtemp(prefix="ptts_bench_extras_")
+    try:
+        json.dump({"sections": sections, "B": B, "T": T, "P": P, "L": L, "greedy_ms_per_step": greedy_ms_per_step,
+                   "cpu_full_b1": cpu_full_b1}, open(os.path.join(d, "request.json"), "w"))
+        if bf16_codes is not None:
+            torch.save(bf16_codes.cpu(), os.path.join(d, "bf16_codes.pt"))
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--extras", d], stdout=subprocess.PIPE, text=True)
+        try:
+            stdout, _ = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            proc.kill()                                   # the exact child, by handle
+            proc.communicate()
+            return {k: {"error": f"extras child exceeded {timeout_s} s and was killed"} for k in sections}
+        lines = [t for t in stdout.splitlines() if t.startswith("{") and t.endswith("}")]
+        if proc.returncode != 0 or not lines:
+            return {k: {"error": f"extras child exited {proc.returncode} without a record"} for k in sections}
+        return json.loads(lines[-1])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -384,12 +576,17 @@ def main():
     ap.add_argument("--cpu-full-b1", action="store_true", help="also time one FULL batch-1 run of the CPU port (minutes)")
     ap.add_argument("--no-dac", action="store_true", help="stop at codec ids (diagnostic; not the headline)")
     ap.add_argument("--no-fp32-pass", action="store_true", help="skip the one timed pass in the bit-exact fp32 mode (N = 1, bf16 runs)")
+    ap.add_argument("--no-sampling-pass", action="store_true", help="skip the configs[3] sampling record (N = 1, bf16 runs)")
+    ap.add_argument("--extras", default=None, help=argparse.SUPPRESS)      # internal: the child that measures the optional records
     ap.add_argument("--force-dp", action="store_true",
                     help="N = 1 through generate_data_parallel on a world-size-1 process group (runs every collective of "
                          "distributed.py on RCCL with one rank; not the headline)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="CPU rehearsal of the N-rank plumbing with a stand-in model (gloo, no GPU, no measurement)")
     args = ap.parse_args()
+    if args.extras:
+        extras_child(args)
+        return
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     scaled = args.workload == "scaled"
@@ -499,6 +696,16 @@ def main():
     audio_s = B * F / cfg.audio_encoder.frame_rate * args.steps * world
     prof = model.engine().profile_read(reset=True)
     dp = dp_report(dist, world, coll_dev, phase, timings, args.steps, 0.0 if plumbing else tokens / dt) if dist is not None else None
+    if dp is not None and world > 1 and rank == 0 and out is not None:
+        # SURVEY section 4 test (5) inside the N > 1 line: ONE extra, untimed generate() of rank 1's slice on
+        # rank 0's own GPU; the codec ids the data-parallel pass gathered for that slice must be the ids one GPU computes for it
+        sl = slice(B, 2 * B)
+        model.phase_times = None
+        model.generate(input_ids=desc[sl], attention_mask=amask[sl], prompt_input_ids=prompt[sl], **kw)
+        mine, theirs = model.last_codes[0].cpu(), out[sl].cpu()
+        dp["equals_single_gpu"] = bool(mine.shape == theirs.shape and torch.equal(mine, theirs))
+        dp["equals_single_gpu_checked"] = f"rank 1's slice (utterances {B}..{2 * B - 1}) re-generated on rank 0 after the timed region: " \
+                                          f"{tuple(mine.shape)} codec ids compared with the gathered ones"
     if rank == 0:
         achieved = (prof.algo_bytes / 1e9) / (prof.total_ms / 1e3) if prof.total_ms > 0 else 0.0
         # HBM traffic of the dominant kernel: NOT a counter reading of this run.  rocprofv3 --pmc passes (separate runs,
@@ -573,26 +780,35 @@ def main():
                 "counters": "profiles/r04_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
         if dp is not None:
             line["data_parallel"] = dp
+            if dp.get("equals_single_gpu") is False:
+                line["invalid"] = "data-parallel codec ids of rank 1's slice differ from a single-GPU generate() of the same slice"
         if plumbing:
-            line["invalid"] = "--plumbing-only: stand-in model on CPU ranks, nothing was measured"
+            line["invalid"] = "--plumbing-only: stand-in model on CPU ranks, nothing was measured" + \
+                              ("; " + line["invalid"] if "invalid" in line else "")
             for k in ("rtf_audio_s_per_wall_s", "decode_loop_tokens_per_s", "ttft_ms_rank0", "decode_loop_roofline_rank0", "roofline",
                       "dac_decode_rank0", "phase_ms_per_step_rank0"):
                 line.pop(k, None)
         line["profile_every"] = args.profile_every    # every n-th decode step of the timed region runs eagerly with events
         if scaled:
             line["not_headline"] = "--workload scaled: BASELINE configs[4]'s per-GPU shard, not the metric's configuration"
-        if world == 1 and args.dtype == "bf16" and not (args.no_fp32_pass or plumbing or args.no_dac or args.force_dp or scaled):
-            try:        # an extra record next to the headline: its failure must not cost the line already measured
-                line["fp32_parity_mode"] = fp32_parity_pass(cfg, sd, dev, desc, amask, prompt, B, T, P, L, pass_codes[-1] if pass_codes else None)
-            except Exception as e:
-                line["fp32_parity_mode"] = {"error": f"{type(e).__name__}: {e}"}
+        sections = []
+        if world == 1 and args.dtype == "bf16" and not (plumbing or args.no_dac or args.force_dp or scaled):
+            if not args.no_fp32_pass:
+                sections.append("fp32_parity_mode")
+            if not args.no_sampling_pass:
+                sections.append("sampling_mode")
         if world == 1 and not (args.no_cpu_baseline or plumbing or args.force_dp or scaled):
-            sd_dec = {k: v for k, v in sd.items() if not k.startswith(("text_encoder.", "audio_encoder."))}
-            try:
-                line["cpu_baseline"] = cpu_baseline(cfg, sd_dec, B, T, P, L, full_b1=args.cpu_full_b1)
-            except Exception as e:
-                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}", "kind": "port"}
-            if line["decode_loop_tokens_per_s"] and "value" in line["cpu_baseline"]:
+            sections.append("cpu_baseline")
+        if sections:
+            # the optional records run in a CHILD process (started, never exec'd) after this process has released its engine: a
+            # fault or hang there cannot cost the headline already measured above
+            codes = pass_codes[-1] if (pass_codes and "fp32_parity_mode" in sections) else None
+            if getattr(model, "_engine", None) is not None:
+                model._engine.close()
+                model._engine = None
+            step_ms = phase["decode_ms"] / args.steps / n_steps if phase["decode_ms"] else None
+            line.update(run_extras(sections, B, T, P, L, codes, step_ms, args.cpu_full_b1))
+            if line.get("decode_loop_tokens_per_s") and "value" in line.get("cpu_baseline", {}):
                 # the static-KV leg first: it is the fair algorithmic baseline; the reference-shaped leg is dominated by the
                 # reference's own torch.cat re-copy of the cache (M:303-304)
                 line["speedup_vs_cpu_decode_loop"] = {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 7
+#define PTTS_ABI_VERSION 8
 
 enum { PTTS_DTYPE_F32 = 0, PTTS_DTYPE_BF16 = 1 };
 
@@ -191,6 +191,17 @@ typedef struct ptts_state {
     int32_t pos, cur_len, prompt_len, n_unfinished, done_len, step_count;
 } ptts_state;
 int ptts_get_state(ptts_engine* e, ptts_state* out_host, void* stream);
+
+/* The same without stopping the stream (ABI v8).  The third-party loop the reference calls at M:2582 / M:2608 tests
+ * `unfinished_sequences.max() == 0` after EVERY step, on the host; here the loop state lives on the device and a blocking read
+ * every few steps would drain the queue of replayed steps.  ptts_state_snapshot enqueues, behind the work already on `stream`, a
+ * copy of the loop state into pinned host slot `slot` (0 .. PTTS_STATE_SLOTS-1) and records an event; ptts_state_poll waits for
+ * THAT event only (work enqueued after the snapshot keeps running) and returns the copy.  A caller that enqueues chunk i + 1
+ * before it polls chunk i's snapshot learns of the end of the run at most two chunks late and never lets the stream run dry.
+ * ptts_state_poll on a slot with no snapshot taken since the last poll is PTTS_E_STATE. */
+#define PTTS_STATE_SLOTS 4
+int ptts_state_snapshot(ptts_engine* e, int32_t slot, void* stream);
+int ptts_state_poll(ptts_engine* e, int32_t slot, ptts_state* out_host);
 
 /* logits of the last executed step [B_eff*K][vocab] fp32 (device pointer owned by the engine), for
  * parity tests; probabilities after warping when sampling. */

@@ -476,8 +476,33 @@ def causal_variants():
              meta=json.dumps(dict(sd_kw=sd_kw, B=B, T=T, P=P, L=L, seed_in=seed_in, guidance_scale=gs)), **extra, **r)
 
 
+def ref_config_cases():
+    """The checkpoint boundary as the REFERENCE's own classes write it (the reference user's entry point is
+    `from_pretrained`, M:1701-1720): for the mini_v0.1 and the tiny architectures, the `config.json` text of the real
+    `ParlerTTSConfig.to_json_string(use_diff=False)` (its `save_pretrained` itself fails under transformers 5.15: `to_diff_dict`
+    instantiates the composite class without sub-configs) and a {parameter name: shape} manifest of the real
+    `ParlerTTSForConditionalGeneration.state_dict()`.  Data only: names, shapes and hyper-parameters, no source text."""
+    for tag, cfg in (("mini", mini_v01_config()), ("tiny", tiny_config())):
+        sd = synthetic_state_dict(cfg, seed=1, parts=("text_encoder", "decoder"))
+        model = ref_shim.build_reference_model(cfg, sd)
+        text = model.config.to_json_string(use_diff=False)
+        with open(os.path.join(OUT, f"ref_config_{tag}.json"), "w") as f:
+            f.write(text)
+        manifest = {k: list(v.shape) for k, v in model.state_dict().items()}
+        with open(os.path.join(OUT, f"ref_state_manifest_{tag}.json"), "w") as f:
+            json.dump({"written_by": "oracle/gen_golden.py --only-ref-config: state_dict() of the real reference class "
+                                     "(codec = stub: descript-audio-codec is absent offline, so no audio_encoder.* entries)",
+                       "n_parameters": int(sum(v.numel() for v in model.state_dict().values())),
+                       "tensors": manifest}, f, indent=1, sort_keys=True)
+        print(f"  ref_config_{tag}.json ({len(text)} chars), ref_state_manifest_{tag}.json ({len(manifest)} tensors)")
+        del model, sd
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-ref-config" in sys.argv:
+        ref_config_cases()
+        return
     if "--only-causal-variants" in sys.argv:
         causal_variants()
         return

@@ -61,9 +61,18 @@ def load_reference():
     orig_m = AutoModel.register.__func__
     AutoConfig.register = staticmethod(lambda model_type, config, exist_ok=False: orig_c(model_type, config, exist_ok=True))
     AutoModel.register = classmethod(lambda cls, config_class, model_class, exist_ok=False: orig_m(cls, config_class, model_class, exist_ok=True))
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    # the repository root holds an alias package of the same name (parler_tts/__init__.py -> parler_tts_amd): evict it and put the
+    # reference tree in front, so that `parler_tts` below IS /root/reference/parler_tts
+    for name in [m for m in sys.modules if m == "parler_tts" or m.startswith("parler_tts.")]:
+        if getattr(sys.modules.get("parler_tts"), "__ptts_alias__", False):
+            del sys.modules[name]
+    if REFERENCE_ROOT in sys.path:
+        sys.path.remove(REFERENCE_ROOT)
+    sys.path.insert(0, REFERENCE_ROOT)
     import parler_tts  # noqa: the real reference
+
+    if not os.path.realpath(parler_tts.__file__).startswith(REFERENCE_ROOT + os.sep):
+        raise RuntimeError(f"`parler_tts` resolved to {parler_tts.__file__}, not to the reference tree")
 
     # shim 4
     parler_tts.ParlerTTSForConditionalGeneration.tie_weights = lambda self, *a, **k: None

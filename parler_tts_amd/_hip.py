@@ -11,13 +11,14 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libparler_tts_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 DTYPE_F32, DTYPE_BF16 = 0, 1
+STATE_SLOTS = 4        # PTTS_STATE_SLOTS
 
 # every symbol include/parler_tts_hip.h declares (tests check the export table against this list)
 EXPORTS = [
     "ptts_last_error", "ptts_abi_version", "ptts_create", "ptts_destroy", "ptts_load_tensor", "ptts_weights_ready",
-    "ptts_t5_encode", "ptts_dac_decode", "ptts_dac_encode", "ptts_set_prompt_embeds", "ptts_set_decoder_mask", "ptts_prefill", "ptts_decode_steps", "ptts_forward_step", "ptts_select_step", "ptts_get_state", "ptts_last_logits",
+    "ptts_t5_encode", "ptts_dac_decode", "ptts_dac_encode", "ptts_set_prompt_embeds", "ptts_set_decoder_mask", "ptts_prefill", "ptts_decode_steps", "ptts_forward_step", "ptts_select_step", "ptts_get_state", "ptts_state_snapshot", "ptts_state_poll", "ptts_last_logits",
     "ptts_set_block_table", "ptts_pool_info", "ptts_set_forced_tokens", "ptts_set_forced_sequence", "ptts_profile_read", "ptts_test_gemm",
     "ptts_debug_stop_after", "ptts_debug_buffer", "ptts_dac_kernel_counts",
 ]
@@ -102,6 +103,8 @@ def load_library() -> C.CDLL:
     lib.ptts_forward_step.argtypes = [vp, vp]
     lib.ptts_select_step.argtypes = [vp, C.POINTER(PttsSampling), vp]
     lib.ptts_get_state.argtypes = [vp, C.POINTER(PttsState), vp]
+    lib.ptts_state_snapshot.argtypes = [vp, i32, vp]
+    lib.ptts_state_poll.argtypes = [vp, i32, C.POINTER(PttsState)]
     lib.ptts_last_logits.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.ptts_set_block_table.argtypes = [vp, C.POINTER(C.c_int32), i32, i32]
     lib.ptts_pool_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]

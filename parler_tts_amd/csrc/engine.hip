@@ -158,6 +158,10 @@ struct ptts_engine {
     const long long* force_seq = nullptr;   // ptts_set_forced_sequence
     long long* own_choice = nullptr;
     StepState* state = nullptr;
+    // ptts_state_snapshot / ptts_state_poll: pinned host copies of the loop state, one event per slot
+    StepState* snap_host = nullptr;
+    hipEvent_t snap_ev[PTTS_STATE_SLOTS] = {};
+    bool snap_pending[PTTS_STATE_SLOTS] = {};
     // DAC decoder (codec): conv0, per block {convT, 3 x (conv7, conv1)}, final conv
     std::vector<ConvLayer> dac;
     std::vector<float*> dac_codebook, dac_proj_w, dac_proj_b;
@@ -1013,6 +1017,8 @@ int ptts_destroy(ptts_engine* e) {
     if (e->stamps) (void)hipFree(e->stamps);
 #endif
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->snap_host) (void)hipHostFree(e->snap_host);
+    for (hipEvent_t ev : e->snap_ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
@@ -1426,6 +1432,33 @@ int ptts_get_state(ptts_engine* e, ptts_state* out, void* stream) {
     PTTS_TRY(enter_stream(e, stream, &s));
     HIP_TRY(hipMemcpyAsync(&st, e->state, sizeof(st), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    out->pos = st.pos; out->cur_len = st.cur_len; out->prompt_len = st.prompt_len;
+    out->n_unfinished = st.n_unfinished; out->done_len = st.done_len; out->step_count = st.step_count;
+    return PTTS_OK;
+}
+
+int ptts_state_snapshot(ptts_engine* e, int32_t slot, void* stream) {
+    if (!e) return fail(PTTS_E_INVALID, "null engine");
+    if (slot < 0 || slot >= PTTS_STATE_SLOTS) return fail(PTTS_E_INVALID, "state slot %d outside 0..%d", slot, PTTS_STATE_SLOTS - 1);
+    if (!e->snap_host) {
+        HIP_TRY(hipHostMalloc((void**)&e->snap_host, sizeof(StepState) * PTTS_STATE_SLOTS, hipHostMallocDefault));
+        for (int i = 0; i < PTTS_STATE_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&e->snap_ev[i], hipEventDisableTiming));
+    }
+    hipStream_t s;
+    PTTS_TRY(enter_stream(e, stream, &s));
+    HIP_TRY(hipMemcpyAsync(&e->snap_host[slot], e->state, sizeof(StepState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(e->snap_ev[slot], s));
+    e->snap_pending[slot] = true;
+    return leave_stream(e, stream, s);
+}
+
+int ptts_state_poll(ptts_engine* e, int32_t slot, ptts_state* out) {
+    if (!e || !out) return fail(PTTS_E_INVALID, "null argument");
+    if (slot < 0 || slot >= PTTS_STATE_SLOTS) return fail(PTTS_E_INVALID, "state slot %d outside 0..%d", slot, PTTS_STATE_SLOTS - 1);
+    if (!e->snap_host || !e->snap_pending[slot]) return fail(PTTS_E_STATE, "no snapshot pending in state slot %d", slot);
+    HIP_TRY(hipEventSynchronize(e->snap_ev[slot]));      // waits for the snapshot only: later work on the stream keeps running
+    e->snap_pending[slot] = false;
+    const StepState st = e->snap_host[slot];
     out->pos = st.pos; out->cur_len = st.cur_len; out->prompt_len = st.prompt_len;
     out->n_unfinished = st.n_unfinished; out->done_len = st.done_len; out->step_count = st.step_count;
     return PTTS_OK;

@@ -708,7 +708,8 @@ hipError_t launch_typed(const GemmArgs& a, hipStream_t stream) {
     }
     // residual projections on whole 32-row workgroups (M <= 16: the half-split grid would launch empty halves; BASELINE configs[4]'s
     // per-GPU shard of 8 utterances): the same kernel with its epilogue fixed at compile time, as the half-split ones above
-    if (!generic_only && !a.force_whole && !a.bias && !a.rowmask && !a.fold && !halves && !a.W2 && a.epi == EPI_RESIDUAL) {
+    // (restricted to M <= 16, what the bit-identity test pins at batch 8: `!halves` alone is also true for N > 2048 at any M - ADVICE r4)
+    if (!generic_only && !a.force_whole && !a.bias && !a.rowmask && !a.fold && !halves && !a.W2 && a.M <= 16 && a.epi == EPI_RESIDUAL) {
         if (nw == 16) return launch_one<P, 16, 1, false, 1, 2, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);
         if (nw == 8) return launch_one<P, 8, 1, false, 1, 2, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);
         return launch_one<P, 4, 1, false, 1, 2, false, EPI_RESIDUAL, ACT_NONE, 0>(a, stream);

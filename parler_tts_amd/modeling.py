@@ -223,6 +223,16 @@ class HipEngine:
         _hip.check(self.lib.ptts_get_state(self.handle, C.byref(st), _stream()))
         return st
 
+    def state_snapshot(self, slot: int) -> None:
+        """Enqueue a copy of the loop state into pinned host slot `slot` behind the work already on the stream (no wait)."""
+        _hip.check(self.lib.ptts_state_snapshot(self.handle, slot, _stream()))
+
+    def state_poll(self, slot: int) -> _hip.PttsState:
+        """The snapshot of `slot`: waits for that copy only, later work on the stream keeps running."""
+        st = _hip.PttsState()
+        _hip.check(self.lib.ptts_state_poll(self.handle, slot, C.byref(st)))
+        return st
+
     def last_logits(self, rows: int, probs: bool = False) -> torch.Tensor:
         """Copy of the last step's logits [rows][vocab] (device -> new torch tensor)."""
         lp, pp = C.c_void_p(), C.c_void_p()
@@ -351,7 +361,11 @@ class DACModel:
             self._own = HipEngine(full, sd, "fp32", self.device, 1, 1, 0, 2, codec_only=True)
 
     def _engine(self) -> HipEngine:
-        return self._own if self._own is not None else self._provider()
+        if self._own is not None:
+            return self._own
+        eng = self._provider()          # the owning model's CURRENT engine (rebuilt after model.to(...)): never a closed handle
+        self.device = eng.device
+        return eng
 
     @torch.no_grad()
     def decode(self, audio_codes, audio_scales=None, padding_mask=None, return_dict=None):
@@ -416,6 +430,8 @@ class ParlerTTSForConditionalGeneration:
         if self.generation_config.bos_token_id is None:
             self.generation_config.bos_token_id = d.bos_token_id  # M:2532 reads it; the recipe leaves it unset
         self.profile_every = 0
+        # generate() without a streamer: decode steps queued between two reads of the device's loop state (EOS criterion)
+        self.eos_poll_steps = 16
         self.phase_times = None   # bench.py: {'t5_prefill_ms','decode_ms','post_ms'} accumulated with syncs at the seams
 
     # ---- construction ----
@@ -425,12 +441,18 @@ class ParlerTTSForConditionalGeneration:
         if not os.path.isdir(path):
             raise OSError(f"{path} is not a local directory (hub downloads are not available here)")
         td = kw.pop("torch_dtype", None)          # the transformers spelling: torch.bfloat16 / torch.float32 (or their names)
-        if td is not None:
-            names = {torch.bfloat16: "bf16", torch.float32: "fp32", "bfloat16": "bf16", "float32": "fp32", "bf16": "bf16", "fp32": "fp32"}
-            if td not in names:
-                raise NotImplementedError(f"torch_dtype={td}: the engine computes in bfloat16 or float32")
-            dtype = names[td]
         cfg = ParlerTTSConfig.from_pretrained(path)
+        names = {torch.bfloat16: "bf16", torch.float32: "fp32", "bfloat16": "bf16", "float32": "fp32", "bf16": "bf16", "fp32": "fp32"}
+        if isinstance(td, str) and td == "auto":
+            # transformers: "auto" = the dtype recorded in the checkpoint's config.json, else the loader's default
+            extra = getattr(cfg, "_extra", {})
+            td = extra.get("torch_dtype", extra.get("dtype"))        # transformers 4.x / 5.x spelling of the same field
+            td = td if td in names else None
+        if td is not None:
+            if td not in names:
+                raise NotImplementedError(f"torch_dtype={td}: the engine computes in bfloat16 (default) or float32; half precision "
+                                          "(float16) is not an engine mode")
+            dtype = names[td]
         sd = normalize_state_dict(load_state_dict_from_dir(path), cfg)
         gen = None
         gpath = os.path.join(path, "generation_config.json")
@@ -469,16 +491,25 @@ class ParlerTTSForConditionalGeneration:
             if dtype not in names:
                 raise NotImplementedError(f"{dtype}: the engine computes in bfloat16 or float32")
             if names[dtype] != self.dtype:
-                if self._engine is not None:
-                    self._engine.close()
-                self.dtype, self._engine, self._dac = names[dtype], None, None
+                self._drop_engine()
+                self.dtype = names[dtype]
         if device is not None:
             dev = torch.device(device)
             if dev.type != "cuda":
                 raise RuntimeError("this engine only runs on an MI355X (device type 'cuda' under ROCm)")
             if dev != self.device:
-                self.device, self._engine, self._dac = dev, None, None
+                self._drop_engine()
+                self.device = dev
         return self
+
+    def _drop_engine(self) -> None:
+        """Release the HIP engine NOW (KV pool, codec workspaces, graphs) instead of at garbage collection; it is rebuilt at the
+        next call.  A codec wrapper handed out earlier (`model.audio_encoder`) stays valid: it asks the model for its engine at
+        every call and is re-bound to the model's device here."""
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = None
+        self._dac = None
 
     def bfloat16(self):
         return self.to(torch.bfloat16)
@@ -524,8 +555,24 @@ class ParlerTTSForConditionalGeneration:
         # steps could only produce pad tokens, so the flag is accepted and changes nothing.
         # every stream handle, lazy allocation and launch below follows the CURRENT device: make it the model's
         with torch.cuda.device(self.device):
-            return self._generate(inputs, generation_config, logits_processor, stopping_criteria, synced_gpus, streamer,
-                                  **kwargs)
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream != 0 or os.environ.get("PTTS_LEGACY_POLL"):
+                return self._generate(inputs, generation_config, logits_processor, stopping_criteria, synced_gpus, streamer,
+                                      **kwargs)
+            # The legacy NULL stream cannot be captured into a hipGraph and every engine call on it is host-synchronous
+            # (csrc/engine.hip: enter_stream / leave_stream).  The call runs on a stream of the model's own instead: it waits
+            # for what the caller has queued on the NULL stream, and the NULL stream waits for it at the end, so the caller
+            # sees the ordering of the stream it called from.
+            if getattr(self, "_side_stream", None) is None or self._side_stream.device != self.device:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            side.wait_stream(cur)
+            try:
+                with torch.cuda.stream(side):
+                    return self._generate(inputs, generation_config, logits_processor, stopping_criteria, synced_gpus,
+                                          streamer, **kwargs)
+            finally:
+                cur.wait_stream(side)
 
     def _generate(self, inputs, generation_config, logits_processor, stopping_criteria, synced_gpus, streamer, **kwargs):
         cfgm, dec = self.config, self.config.decoder
@@ -805,12 +852,31 @@ class ParlerTTSForConditionalGeneration:
             remaining = 0
         # a streamer is fed one column per decoding step (M:2540-2541 + the third-party loop), but the host only polls the
         # device every `poll_steps` steps (streamer attribute, default 8): one state read-back and one copy per poll
-        chunk = max(1, int(getattr(streamer, "poll_steps", 8))) if streamer is not None else 128
+        # Without a streamer the loop state is read through PIPELINED snapshots (ptts_state_snapshot / ptts_state_poll): chunk
+        # i + 1 is queued before chunk i's snapshot is awaited, so the device never runs dry and an EOS-terminated call runs at
+        # most 2 * eos_poll_steps - 1 steps past its last token (rounds 1-4 read the state with a blocking copy every 128 steps:
+        # up to 127 extra steps, ~64 on average).  The third-party loop tests `unfinished_sequences.max() == 0` after every step.
+        legacy_poll = bool(os.environ.get("PTTS_LEGACY_POLL"))      # A/B switch: rounds 1-4's blocking read every 128 steps
+        poll_eos = streamer is None and gen.eos_token_id is not None and not legacy_poll
+        chunk = max(1, int(getattr(streamer, "poll_steps", 8))) if streamer is not None else \
+            (max(1, int(self.eos_poll_steps)) if poll_eos else 128)
         fed = start_len                                   # columns already handed to the streamer
+        pending, slot = None, 0                           # snapshot slot not polled yet / next slot to use
         while remaining > 0:
             n = min(chunk, remaining)
             eng.decode_steps(n, sp, self.profile_every)
             remaining -= n
+            if poll_eos:
+                eng.state_snapshot(slot)
+                if pending is not None:
+                    st = eng.state_poll(pending)
+                    if st.done_len:
+                        L_out = st.done_len
+                        eng.state_poll(slot)              # retire the snapshot just taken
+                        pending = None
+                        break
+                pending, slot = slot, (slot + 1) % _hip.STATE_SLOTS
+                continue
             if streamer is not None:
                 st = eng.state()
                 upto = st.done_len or st.cur_len
@@ -822,11 +888,15 @@ class ParlerTTSForConditionalGeneration:
                 if st.done_len:
                     L_out = st.done_len
                     break
-            elif gen.eos_token_id is not None:
+            elif legacy_poll and gen.eos_token_id is not None:
                 st = eng.state()
                 if st.done_len:
                     L_out = st.done_len
                     break
+        if pending is not None:                           # the run's last chunk
+            st = eng.state_poll(pending)
+            if st.done_len:
+                L_out = st.done_len
         if streamer is not None:
             streamer.end()
         torch.cuda.current_stream().synchronize()

@@ -26,6 +26,7 @@ def test_gpus_2_starts_two_ranks_and_ends_with_rank0_json_line():
     dp = line["data_parallel"]
     assert dp["ranks"] == 2 and dp["backend"] == "gloo"
     assert set(dp["per_rank_min_max"]) >= {"scatter_ms_last_pass", "generate_ms_last_pass", "gather_ms_last_pass"}
+    assert dp["equals_single_gpu"] is True                    # rank 1's slice re-generated on rank 0 gives the gathered ids
     assert line["steps"] == 2 and line["warmup"] == 1 and line["passes_bit_identical_rank0"] is True
     # a rehearsal can not be mistaken for a measurement
     assert line["value"] == 0.0 and "invalid" in line and "roofline" not in line and line["data"].startswith("none")
@@ -50,3 +51,25 @@ def test_launcher_rank_count_must_agree_with_the_flag():
     # --gpus 1 inside a 2-rank launch is refused as well (it used to be accepted silently when WORLD_SIZE was 1)
     r = _run(["--gpus", "1", "--plumbing-only"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
     assert r.returncode != 0 and "must agree" in r.stderr
+
+
+def test_eight_rank_rehearsal_of_the_scale_run():
+    """The driver's SCALE run is `--gpus 8` on a node the builder never sees: the same launcher, process group, scatter of the id
+    slices and padded gather with 8 CPU ranks (only 2 ranks were rehearsed before)."""
+    r = _run(["--gpus", "8", "--plumbing-only", "--batch", "2", "--max-length", "12", "--steps", "1", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8" and line["config"]["global_batch"] == 16
+    dp = line["data_parallel"]
+    assert dp["ranks"] == 8 and dp["equals_single_gpu"] is True
+    assert sum('"metric"' in ln for ln in r.stdout.splitlines()) == 1
+
+
+def test_a_rank_that_computes_something_else_invalidates_the_line():
+    """`data_parallel.equals_single_gpu` is a check, not a constant: a rank 1 whose codec ids differ from what rank 0 computes for
+    the same slice must turn the line invalid (SURVEY section 4 test (5), inside the N > 1 line)."""
+    r = _run(["--gpus", "2", "--plumbing-only", "--batch", "3", "--max-length", "12", "--steps", "1", "--warmup", "0"],
+             env_extra={"PTTS_PLUMBING_CORRUPT_RANK": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert line["data_parallel"]["equals_single_gpu"] is False and "differ from a single-GPU generate()" in line["invalid"]

@@ -369,7 +369,7 @@ def run_forced_long(name, dtype, batch_pad=0):
 
 
 @pytest.mark.parametrize("name", ["tinylong_greedy", "minilong_greedy", "minilong2580_greedy"])
-def test_fp32_long_horizon_against_the_reference(hip, name):
+def test_fp32_long_horizon_against_the_reference(hip, name, capsys):
     """L = 2580 (tiny shape: 41 KV pages, positions > 2048), L = 512 (mini_v0.1 shape) and L = 2580 at the mini_v0.1 shape
     (`minilong2580_greedy`: 24 layers x 16 heads over all 41 KV pages - BASELINE configs[1]'s exact decoder at its full
     horizon) runs of the REAL reference.  fp32 engine, teacher-forced: logits of the sampled steps (first, EVERY page
@@ -380,11 +380,24 @@ def test_fp32_long_horizon_against_the_reference(hip, name):
     assert d.max() < 2e-4, (d.max(), d.reshape(d.shape[0], -1).max(1))
     L = int(f["max_length"])
     free = free_positions(f["pattern"], L - 1)
-    ok = free & (f["margins"] >= 5e-4)
+    gold = f["raw_ids"][:, 1:].T
+    ok = free & (f["margins"] >= FP32_ARGMAX_MARGIN)
     assert ok.mean() > 0.5 * free.mean()
-    assert np.array_equal(own[ok], f["raw_ids"][:, 1:].T[ok])
+    assert np.array_equal(own[ok], gold[ok])
     last = f["logit_steps"] >= L - 9
     assert last.sum() >= 6 and d[last].max() < 2e-4
+    # the kept argmaxes the 5e-4 rule skips: what did the engine choose THERE?  A flip is legitimate only
+    # where the reference's own top-2 gap is below twice the largest logit difference measured in this very run (two logits
+    # moving towards each other by d.max() each); everything else must agree, and the counts go on the record.
+    sub = free & ~ok
+    flips = sub & (own != gold)
+    with capsys.disabled():
+        print(f"\n[fp32 forced] {name}: {int(free.sum())} kept argmaxes, {int(ok.sum())} with a reference margin >= {FP32_ARGMAX_MARGIN:g} "
+              f"(all equal), {int(sub.sum())} below it of which the engine's own choice differs at {int(flips.sum())}"
+              + (f" (largest reference margin at a differing choice {float(f['margins'][flips].max()):.2e})" if flips.any() else "")
+              + f"; max |dlogit| at the sampled steps {d.max():.2e}, smallest kept margin {float(f['margins'][free].min()):.2e}")
+    strict = free & (f["margins"] >= 2 * float(d.max()))
+    assert np.array_equal(own[strict], gold[strict]), float(f["margins"][strict & (own != gold)].max())
 
 
 def _bf16_long_reference(name, f):
@@ -498,19 +511,15 @@ def test_bf16_engine_is_at_least_as_close_to_the_fp32_reference_as_the_reference
         assert float(f["margins"][miss].max()) < 2 * summ["max_abs_dlogit"], float(f["margins"][miss].max())
 
 
-def test_bf16_free_running_audit_against_the_fp32_reference_ids(hip, capsys):
-    """What the benchmark's precision does to the ids when nothing is forced: the bf16 engine on `minilong2580_greedy`'s inputs
-    (mini_v0.1 shape, 2579 steps), free-running.  Per utterance, the first column where one of its codebook rows leaves the fp32
-    reference's ids must be a step the reference itself decides by less than 2 x the bf16 bound (the reference-in-bf16's max
-    |dlogit|, from the fixture); after that column the utterance follows another greedy path, so the agreement fraction is
-    printed, not asserted."""
+def _free_running_audit(name, dtype):
+    """The engine on a long fixture's inputs with NOTHING forced.  Returns (fixture, per-utterance report, L): for every utterance
+    (b, first differing step or None, the reference's own top-2 gap at the codebook rows whose ids first differ, fraction of the
+    kept ids equal to the reference's over the whole run)."""
     from parler_tts_amd import _hip
     from parler_tts_amd.delay_pattern import build_delay_pattern_mask
 
-    name = "minilong2580_greedy"
     f, meta = load_case(name)
-    bound = _ref_bf16_case(name)[4]["max_abs_dlogit"]
-    cfg, model = model_for(name, meta, "bf16")
+    cfg, model = model_for(name, meta, dtype)
     desc, amask, prompt, pmask = case_inputs(f)
     enc = torch.from_numpy(f["enc_t5"])
     K, B, L = cfg.decoder.num_codebooks, enc.shape[0], int(f["max_length"])
@@ -540,12 +549,45 @@ def test_bf16_free_running_audit_against_the_fp32_reference_ids(hip, capsys):
         c = int(cols[0])                                              # step c filled column c + 1
         m = float(f["margins"][c][rows][diff[rows][:, c]].max())      # the reference's own top-2 gap where the ids first differ
         report.append((b, c, m, float(1.0 - diff[rows].mean() / max(free[rows].mean(), 1e-9))))
-        assert m < 2 * bound, (b, c, m, bound)
+    return f, report, L
+
+
+def test_bf16_free_running_audit_against_the_fp32_reference_ids(hip, capsys):
+    """What the benchmark's precision does to the ids when nothing is forced: the bf16 engine on `minilong2580_greedy`'s inputs
+    (mini_v0.1 shape, 2579 steps), free-running.  Per utterance, the first column where one of its codebook rows leaves the fp32
+    reference's ids must be a step the reference itself decides by less than 2 x the bf16 bound (the reference-in-bf16's max
+    |dlogit|, from the fixture); after that column the utterance follows another greedy path, so the agreement fraction is
+    printed, not asserted."""
+    name = "minilong2580_greedy"
+    bound = _ref_bf16_case(name)[4]["max_abs_dlogit"]
+    f, report, L = _free_running_audit(name, "bf16")
+    for b, c, m, frac in report:
+        assert c is None or m < 2 * bound, (b, c, m, bound)
     with capsys.disabled():
         for b, c, m, frac in report:
             print(f"\n[bf16 free run] utterance {b}: " + ("ids equal to the fp32 reference over the whole run" if c is None else
                   f"first differing step {c} of {L - 1} (reference margin there {m:.2e}, 2 x bf16 bound {2 * bound:.3f}); "
                   f"kept ids equal to the fp32 reference's: {frac * 100:.1f} %"))
+
+
+FP32_ARGMAX_MARGIN = 5e-4        # below this top-2 gap of the REFERENCE an fp32 re-association may flip the argmax (logits agree to 2e-4)
+
+
+@pytest.mark.parametrize("name", ["minilong_greedy", "minilong2580_greedy"])
+def test_fp32_free_running_audit_against_the_fp32_reference_ids(hip, name, capsys):
+    """The bit-exact claim, free-running: the fp32 engine on the REAL reference's long runs at the mini_v0.1
+    shape (L = 512 and the benchmark's full horizon L = 2580, 24 layers x 16 heads over all 41 KV pages), nothing forced.  Per
+    utterance the ids must EQUAL the reference's up to the first column that the reference itself decides by less than 5e-4
+    (`margins` of the fixture: the top-2 gap of every argmax of the reference run); an utterance that leaves the reference's ids
+    at a step with a margin >= 5e-4 fails the test.  The first differing step and the agreement over the whole run are printed."""
+    f, report, L = _free_running_audit(name, "fp32")
+    with capsys.disabled():
+        for b, c, m, frac in report:
+            print(f"\n[fp32 free run] {name} utterance {b}: " + (f"ids EQUAL to the reference over all {L - 1} steps" if c is None else
+                  f"ids equal to the reference up to step {c} of {L - 1}, which the reference decides by {m:.2e} (< {FP32_ARGMAX_MARGIN:g}); "
+                  f"kept ids equal over the whole run: {frac * 100:.2f} %"))
+    for b, c, m, frac in report:
+        assert c is None or m < FP32_ARGMAX_MARGIN, f"utterance {b} leaves the reference's ids at step {c} where the reference's margin is {m:.3e}"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1514,6 +1556,10 @@ def test_from_pretrained_roundtrip_with_weight_norm(hip, tmp_path):
     model.save_pretrained(str(again))
     model2 = ParlerTTSForConditionalGeneration.from_pretrained(str(again), torch_dtype=torch.float32)     # the transformers spelling
     assert model2.generation_config.max_length == 24
+    # torch_dtype="auto" (transformers: the dtype recorded in config.json, else the default): no record here -> the engine default
+    assert ParlerTTSForConditionalGeneration.from_pretrained(str(again), torch_dtype="auto").dtype == "bf16"
+    with pytest.raises(NotImplementedError):
+        ParlerTTSForConditionalGeneration.from_pretrained(str(again), torch_dtype=torch.float16)
     model2.generate(input_ids=desc, attention_mask=amask, prompt_input_ids=prompt)
     assert np.array_equal(model2.last_codes[0].cpu().numpy(), f["codes"])
     del model2
@@ -2075,9 +2121,14 @@ def test_model_to_dtype_switches_the_engine_mode(hip):
     wav16 = model.generate(**kw)
     assert wav16.shape[0] == desc.shape[0] and bool(torch.isfinite(wav16).all())
     assert (model.last_codes[0].cpu().numpy() == f["codes"]).mean() > 0.8          # bf16: close, not bit-exact
+    codec = model.audio_encoder                     # a wrapper fetched BEFORE the switch: it must follow the model
+    old_engine = model._engine
     model.to("cuda:0", torch.float32)
+    assert not old_engine.handle.value                                          # released NOW, not at garbage collection
+    wav_c = codec.decode(torch.from_numpy(f["codes"])[None]).audio_values       # re-binds to the rebuilt engine, no freed handle
     model.generate(**kw)
     assert model.dtype == "fp32" and np.array_equal(model.last_codes[0].cpu().numpy(), f["codes"])
+    assert codec._engine() is model._engine and wav_c.shape[-1] == f["codes"].shape[-1] * cfg.audio_encoder.hop_length
     with pytest.raises(NotImplementedError):
         model.half()
     del model
@@ -2392,6 +2443,62 @@ def test_min_length_and_min_new_tokens_suppress_eos(hip):
         assert got.shape == want.shape and torch.equal(got, want), kw
     with pytest.raises(NotImplementedError):       # the reference's processor order makes the guidance combine NaN there
         model.generate(**{**kw0, "guidance_scale": 3.0, "min_length": bound})
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_eos_terminated_call_stops_within_the_advertised_poll_window(hip):
+    """VERDICT r4 item 6.  The third-party loop tests `unfinished_sequences.max() == 0` after EVERY step (M:2582 / M:2608); here the
+    loop state lives on the device and generate() reads it through pipelined snapshots every `eos_poll_steps` steps
+    (ptts_state_snapshot / ptts_state_poll: chunk i + 1 is queued before chunk i's snapshot is awaited), so a call that ends on
+    EOS runs at most 2 * eos_poll_steps - 1 steps past its last column (rounds 1-4: a blocking read every 128 steps).  A tiny model
+    whose every head prefers EOS as soon as `min_length` allows it: the ids must equal the oracle run with the same processor, for
+    every poll interval, and the device's step counter must stay inside the window."""
+    from oracle import cpu_ref
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+
+    f, meta = load_case("tiny_eos_free")
+    cfg, sd0 = state_dict_for("tiny_eos_free", meta)
+    desc, amask, prompt, _ = case_inputs(f)
+    eos, K, D = cfg.decoder.eos_token_id, cfg.decoder.num_codebooks, cfg.decoder.hidden_size
+    enc = torch.from_numpy(f["enc_t5"])
+    sd = dict(sd0)
+    sd["decoder.model.decoder.layer_norm.bias"] = sd["decoder.model.decoder.layer_norm.bias"] + 1.0
+    for k in range(K):                                   # logit[eos] ~ sum(final LayerNorm output) ~ D: far above every other logit
+        h = sd[f"decoder.lm_heads.{k}.weight"].clone()
+        h[eos] = 1.0
+        sd[f"decoder.lm_heads.{k}.weight"] = h
+    L, bound = 200, 24
+
+    def min_len_proc(ids, scores):
+        if ids.shape[-1] < bound:
+            scores = scores.clone()
+            scores[:, eos] = -float("inf")
+        return scores
+
+    want = cpu_ref.generate_ids(cfg, sd, enc, amask, prompt, None, L, logits_processor=[min_len_proc])["raw_ids"]
+    done_len = want.shape[1]
+    assert done_len == bound + 1 and bool((want[:, -1] == eos).all())          # every row ends with the first allowed EOS
+    _models.clear()
+    torch.cuda.empty_cache()
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="fp32", device="cuda:0")
+    kw = dict(encoder_outputs=(enc,), attention_mask=amask, prompt_input_ids=prompt, do_sample=False, max_length=L,
+              min_length=bound, return_raw_ids=True)
+    assert model.eos_poll_steps == 16
+    for poll in (16, 4, 1, 128):
+        model.eos_poll_steps = poll
+        model.generate(**kw)
+        got = model.last_raw_ids.cpu()
+        assert got.shape == want.shape and torch.equal(got, want), poll
+        st = model.engine().state()
+        steps_needed = done_len - 1
+        assert st.done_len == done_len and steps_needed <= st.step_count <= min(steps_needed + 2 * poll - 1, L - 1), (poll, st.step_count)
+    # the blocking read is unchanged and a slot with no snapshot pending is an error, not a stale answer
+    eng = model.engine()
+    eng.state_snapshot(2)
+    assert eng.state_poll(2).done_len == done_len
+    with pytest.raises(Exception):
+        eng.state_poll(2)
     del model
     torch.cuda.empty_cache()
 
