@@ -195,8 +195,9 @@ int ptts_get_state(ptts_engine* e, ptts_state* out_host, void* stream);
 /* The same without stopping the stream (ABI v8).  The third-party loop the reference calls at M:2582 / M:2608 tests
  * `unfinished_sequences.max() == 0` after EVERY step, on the host; here the loop state lives on the device and a blocking read
  * every few steps would drain the queue of replayed steps.  ptts_state_snapshot enqueues, behind the work already on `stream`, a
- * copy of the loop state into pinned host slot `slot` (0 .. PTTS_STATE_SLOTS-1) and records an event; ptts_state_poll waits for
- * THAT event only (work enqueued after the snapshot keeps running) and returns the copy.  A caller that enqueues chunk i + 1
+ * one-thread kernel that copies the loop state into pinned host-mapped slot `slot` (0 .. PTTS_STATE_SLOTS-1) and stamps it;
+ * ptts_state_poll watches THAT stamp from the host (no runtime call on the stream: work enqueued after the snapshot keeps
+ * running) and returns the copy.  A caller that enqueues chunk i + 1
  * before it polls chunk i's snapshot learns of the end of the run at most two chunks late and never lets the stream run dry.
  * ptts_state_poll on a slot with no snapshot taken since the last poll is PTTS_E_STATE. */
 #define PTTS_STATE_SLOTS 4

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <set>
 #include <string>
@@ -159,9 +160,11 @@ struct ptts_engine {
     long long* own_choice = nullptr;
     StepState* state = nullptr;
     // ptts_state_snapshot / ptts_state_poll: pinned host copies of the loop state, one event per slot
-    StepState* snap_host = nullptr;
-    hipEvent_t snap_ev[PTTS_STATE_SLOTS] = {};
-    bool snap_pending[PTTS_STATE_SLOTS] = {};
+    int* snap_host = nullptr;               // pinned, host-mapped: [PTTS_STATE_SLOTS][8 ints] (6 state fields, pad, sequence stamp)
+    int* snap_dev = nullptr;                // the same memory as the device sees it
+    int snap_seq = 0;
+    int snap_want[PTTS_STATE_SLOTS] = {};   // stamp each slot waits for (0 = nothing pending)
+    hipStream_t snap_stream[PTTS_STATE_SLOTS] = {};
     // DAC decoder (codec): conv0, per block {convT, 3 x (conv7, conv1)}, final conv
     std::vector<ConvLayer> dac;
     std::vector<float*> dac_codebook, dac_proj_w, dac_proj_b;
@@ -1018,7 +1021,6 @@ int ptts_destroy(ptts_engine* e) {
 #endif
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     if (e->snap_host) (void)hipHostFree(e->snap_host);
-    for (hipEvent_t ev : e->snap_ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
@@ -1437,30 +1439,58 @@ int ptts_get_state(ptts_engine* e, ptts_state* out, void* stream) {
     return PTTS_OK;
 }
 
+// One thread copies the loop state into a slot of pinned, host-mapped memory and stamps it with the caller's sequence number
+// (system-scope release: the fields are visible to the host before the stamp is).  A launch, not a copy: a device-to-host
+// hipMemcpyAsync between two graph replays cost the stream 65-105 us per poll (round 5 A/B: decode pass +0.3-0.5 % at one poll per
+// 16 steps), a one-thread kernel costs a kernel boundary.
+__global__ void snapshot_kernel(const StepState* st, volatile int* dst, int seq) {
+    if (threadIdx.x == 0) {
+        dst[0] = st->pos; dst[1] = st->cur_len; dst[2] = st->prompt_len; dst[3] = st->n_unfinished; dst[4] = st->done_len;
+        dst[5] = st->step_count;
+        __atomic_store_n(const_cast<int*>(dst) + 7, seq, __ATOMIC_RELEASE);       // system scope on fine-grained host memory
+    }
+}
+
 int ptts_state_snapshot(ptts_engine* e, int32_t slot, void* stream) {
     if (!e) return fail(PTTS_E_INVALID, "null engine");
     if (slot < 0 || slot >= PTTS_STATE_SLOTS) return fail(PTTS_E_INVALID, "state slot %d outside 0..%d", slot, PTTS_STATE_SLOTS - 1);
     if (!e->snap_host) {
-        HIP_TRY(hipHostMalloc((void**)&e->snap_host, sizeof(StepState) * PTTS_STATE_SLOTS, hipHostMallocDefault));
-        for (int i = 0; i < PTTS_STATE_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&e->snap_ev[i], hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&e->snap_host, 32 * PTTS_STATE_SLOTS, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(e->snap_host, 0, 32 * PTTS_STATE_SLOTS);
+        HIP_TRY(hipHostGetDevicePointer((void**)&e->snap_dev, e->snap_host, 0));
     }
     hipStream_t s;
     PTTS_TRY(enter_stream(e, stream, &s));
-    HIP_TRY(hipMemcpyAsync(&e->snap_host[slot], e->state, sizeof(StepState), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(e->snap_ev[slot], s));
-    e->snap_pending[slot] = true;
+    const int seq = ++e->snap_seq;
+    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(64), 0, s, e->state, e->snap_dev + 8 * slot, seq);
+    HIP_TRY(hipGetLastError());
+    e->snap_want[slot] = seq;
+    e->snap_stream[slot] = s;
     return leave_stream(e, stream, s);
 }
 
 int ptts_state_poll(ptts_engine* e, int32_t slot, ptts_state* out) {
     if (!e || !out) return fail(PTTS_E_INVALID, "null argument");
     if (slot < 0 || slot >= PTTS_STATE_SLOTS) return fail(PTTS_E_INVALID, "state slot %d outside 0..%d", slot, PTTS_STATE_SLOTS - 1);
-    if (!e->snap_host || !e->snap_pending[slot]) return fail(PTTS_E_STATE, "no snapshot pending in state slot %d", slot);
-    HIP_TRY(hipEventSynchronize(e->snap_ev[slot]));      // waits for the snapshot only: later work on the stream keeps running
-    e->snap_pending[slot] = false;
-    const StepState st = e->snap_host[slot];
-    out->pos = st.pos; out->cur_len = st.cur_len; out->prompt_len = st.prompt_len;
-    out->n_unfinished = st.n_unfinished; out->done_len = st.done_len; out->step_count = st.step_count;
+    if (!e->snap_host || !e->snap_want[slot]) return fail(PTTS_E_STATE, "no snapshot pending in state slot %d", slot);
+    volatile int* src = e->snap_host + 8 * slot;
+    const int want = e->snap_want[slot];
+    // the host watches the stamp in pinned memory: no runtime call touches the stream, later work on it keeps running.  The steps in
+    // front of a snapshot take milliseconds, so the wait sleeps in short naps; after ~20 s without the stamp the stream itself is
+    // asked (a failed launch surfaces as its error instead of an endless wait).
+    for (long spins = 0; __atomic_load_n(const_cast<int*>(src) + 7, __ATOMIC_ACQUIRE) != want; ++spins) {
+        if (spins < 2000) continue;
+        struct timespec ts = {0, 50000};
+        nanosleep(&ts, nullptr);
+        if (spins > 2000 + 400000) {
+            HIP_TRY(hipStreamSynchronize(e->snap_stream[slot]));
+            if (__atomic_load_n(const_cast<int*>(src) + 7, __ATOMIC_ACQUIRE) != want)
+                return fail(PTTS_E_HIP, "state snapshot %d never arrived", want);
+        }
+    }
+    e->snap_want[slot] = 0;
+    out->pos = src[0]; out->cur_len = src[1]; out->prompt_len = src[2];
+    out->n_unfinished = src[3]; out->done_len = src[4]; out->step_count = src[5];
     return PTTS_OK;
 }
 

@@ -859,7 +859,7 @@ class ParlerTTSForConditionalGeneration:
         legacy_poll = bool(os.environ.get("PTTS_LEGACY_POLL"))      # A/B switch: rounds 1-4's blocking read every 128 steps
         poll_eos = streamer is None and gen.eos_token_id is not None and not legacy_poll
         chunk = max(1, int(getattr(streamer, "poll_steps", 8))) if streamer is not None else \
-            (max(1, int(self.eos_poll_steps)) if poll_eos else 128)
+            (max(1, int(os.environ.get("PTTS_EOS_POLL_STEPS", self.eos_poll_steps))) if poll_eos else 128)
         fed = start_len                                   # columns already handed to the streamer
         pending, slot = None, 0                           # snapshot slot not polled yet / next slot to use
         while remaining > 0:
