@@ -24,330 +24,10 @@
 #include <cstdlib>
 
 namespace {
-
-constexpr int NWAVES = 8;
-constexpr int UNR = 4;     // measured: 2, 4 and 8 tiles per burst stream equally fast
-
-template <typename P> struct KVLoad;
-template <> struct KVLoad<PBF16> {
-    static constexpr int LPT = 8;   // lanes per token row
-    static constexpr int EPL = 8;
-    typedef u32x4 raw_t;
-    static __device__ inline void unpack(const raw_t& r, float* f) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t w = r[i];
-            f[2 * i] = __builtin_bit_cast(float, w << 16);
-            f[2 * i + 1] = __builtin_bit_cast(float, w & 0xffff0000u);
-        }
-    }
-};
-template <> struct KVLoad<PF32> {
-    static constexpr int LPT = 16;
-    static constexpr int EPL = 4;
-    typedef f32x4 raw_t;
-    static __device__ inline void unpack(const raw_t& r, float* f) {
-        // (a bit_cast of an ext-vector ELEMENT lvalue reads element 0 for every index under hipcc 7.2:
-        //  keep this a plain element copy)
-        f[0] = r[0]; f[1] = r[1]; f[2] = r[2]; f[3] = r[3];
-    }
-};
-
-// SELF only names the instantiation (self- vs cross-attention launches show up separately in rocprof)
-// SPEC = 1 (experiment, PTTS_ATTN_SPEC=1): identity page table and no look-ahead-QKV prologue fixed at compile time.  The
-// generic instance steps over those two blocks (page-id copy loops, the LayerNorm-finishing prologue) with taken branches;
-// round-3 prologue stamps read 3000 cycles between "first K burst issued" and "pass 1 starts" and the specialisation was
-// built to remove them - it measured slower than the generic instance (attn_decode_launch), so it is not the default.
-template <typename P, typename OP, bool SELF, int SPEC = 0>
-__global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a) {
-    typedef typename P::elem_t elem_t;
-    typedef KVLoad<P> L;
-    typedef typename L::raw_t raw_t;
-    constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT;
-    constexpr int STRIDE = NWAVES * UNR;                          // tiles between two bursts of one wave
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef PTTS_STAMPS
-    // 0 realtime at entry, 1 cycles at entry, 2 first K burst issued, 3 scores done (pass 1), 4 softmax done, 5 P.V done,
-    // 6 output stored, 7 realtime at exit
-    unsigned long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const StampRef stref = a.stamps;
-    stv[0] = stamp_realtime();
-    stv[1] = stamp_cycles();
-#endif
-    float* sc = reinterpret_cast<float*>(smem);                   // [S_cap] scores -> probabilities
-    float* red = sc + a.s_cap;                                    // [NWAVES][64] partial outputs
-    float* wred = red + NWAVES * 64;                              // [NWAVES] cross-wave scalars
-    int* pages = reinterpret_cast<int*>(wred + NWAVES);           // [max_blocks] this utterance's page ids
-
-#ifndef PTTS_EXP_NO_ATTN_PIN
-    // every kernel-argument field of the prologue in ONE scalar-memory round trip (hipcc otherwise fetches them piecemeal)
-    asm volatile("" :: "s"(a.q), "s"(a.pool.base), "s"(a.pool.block_table), "s"(a.state), "s"(a.bias), "s"(a.unfinished), "s"(a.ofrag),
-                 "s"(a.ldq), "s"(a.layer), "s"(a.len), "s"(a.len_from_state), "s"(a.pool.max_blocks), "s"(a.pool.H), "s"(a.pool.n_pages),
-                 "s"(a.rows_per_utt), "s"(a.alive_k), "s"(a.alive_b), "s"(a.lnfix_qkv), "s"(a.s_cap), "s"(a.D));
-#endif
-#ifdef PTTS_STAMPS_ATTN_PROLOGUE
-    stv[2] = stamp_cycles();       // kernel arguments in SGPRs
-#endif
-    const int h = blockIdx.x, b = blockIdx.y;                    // b: query row; bu: the utterance whose cache it reads
-    const int bu = b / a.rows_per_utt;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tt = lane / LPT, c = lane % LPT;                    // token-in-tile, 16-byte chunk of the row
-    const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
-    const bool ident = SPEC == 1 ? true : a.pool.block_table == nullptr;      // identity table: page of block i is bu * max_blocks + i
-    const bool lnq = SPEC == 1 ? false : a.lnfix_qkv != 0;                    // look-ahead QKV prologue
-    const int page0 = bu * a.pool.max_blocks;
-    const size_t page_elems = a.pool.page_elems();       // stride between two pages inside this head's K (or V) slab
-    const size_t head_off = (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() + c * EPL;
-    const size_t v_off = a.pool.kv_elems();
-
-    // The loads that feed the context length and the query are stated FIRST, so that they are older than the key tiles
-    // below (vector-memory results return in issue order: a flag queued behind an HBM tile would wait for it).
-    int pos_ld = 0;
-    // scalar_load invariant (ptts_common.h): this kernel writes neither StepState nor the finished flags (advance / select do)
-    if (a.len_from_state) pos_ld = scalar_load_int(&a.state->pos);
-    int uflag[16];               // scalar loads too (the flag array is over-allocated by 16 ints: engine.hip)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) uflag[k] = 1;
-    if (a.unfinished) {
-        const int* u = a.unfinished + (bu % a.alive_b) * a.alive_k;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) uflag[k] = scalar_load_int(u + k);
-    }
-    float q[EPL];
-    if (!lnq) {
-        // (the 64 query values are uniform over the workgroup; fetching them through the scalar cache - so that they do not queue
-        // in the CU's vector-memory FIFO behind key tiles - and selecting each lane's chunk with 56 v_cndmask was measured
-        // slower: 29.0 -> 29.9 us per launch.)
-        const float* qp = a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL;
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) q[j] = qp[j];
-    }
-#ifdef PTTS_STAMPS_ATTN_PROLOGUE
-    stv[3] = stamp_cycles();       // state / flags / q requested (the stamp's own wait covers the scalar ones)
-#endif
-    // Early K burst: under the identity page table the addresses of the wave's first UNR key tiles depend on nothing but
-    // kernel arguments, so they go out BEFORE the context length is known (state->pos and the finished-utterance flags are
-    // dependent trips to memory: 1.5 us from kernel entry to the first K load in the round-3 stamps).  Token indices are
-    // clamped to the utterance's page run (capacity) instead of S - 1; rows at or past S may hold anything - their scores
-    // are never written (score_burst tests tok < S) and no V tile is requested before S is known.
-    const bool early = ident && !lnq;
-    raw_t bufA[UNR], bufB[UNR];
-    if (early) {
-        const int cap = a.pool.max_blocks * PTTS_PAGE_TOKENS - 1;
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            int tok = (w + u * NWAVES) * TPW + tt;
-            if (tok > cap) tok = cap;
-            const raw_t* src = reinterpret_cast<const raw_t*>(pool + (size_t)(page0 + (tok >> 6)) * page_elems + head_off +
-                                                              (size_t)(tok & 63) * PTTS_HEAD_DIM);
-            bufA[u] = __builtin_nontemporal_load(src);
-        }
-    }
-#ifdef PTTS_STAMPS_ATTN_PROLOGUE
-    stv[4] = stamp_cycles();       // q, state, flags requested; early K burst issued (the stamp waits for the scalar loads)
-#endif
-    int S = a.len_from_state ? (pos_ld + 1) : a.len;
-    const int pos_append = S - 1;                                 // cache position of this step's own k / v (append-only cache)
-    if (a.unfinished) {                                           // finished utterance: one key instead of the whole cache
-        int alive = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) alive |= k < a.alive_k ? uflag[k] : 0;
-        // codebooks 16 .. 31 (ptts_create accepts up to 32; under the delay pattern the HIGHEST codebooks finish last): a tail
-        // of scalar loads that a model with <= 16 codebooks never enters
-        for (int k = 16; k < a.alive_k; ++k) alive |= scalar_load_int(a.unfinished + (bu % a.alive_b) * a.alive_k + k);
-        if (!alive) S = 1;
-    }
-
-    const float* bias = a.bias ? a.bias + (size_t)bu * a.ld_bias : nullptr;
-    // page ids once into LDS: KV addresses then depend on no global load
-    if (!ident)
-        for (int i = tid; i < a.pool.max_blocks; i += NWAVES * 64) pages[i] = a.pool.block_table[bu * a.pool.max_blocks + i];
-    if (lnq) {
-        // Look-ahead QKV: `a.q` is the raw product x.Wqkv'^T this head's slices of which still need the LayerNorm of the
-        // folded projection, rstd * (raw - mean * c1) + c2, from the per-block statistics the producing launch wrote.
-        // Waves 0..2 take q, k, v (64 values each): q goes to LDS (scaled), k and v are appended to the cache at
-        // the step's own position (pos_append: NOT the shortened S - 1 of a finished utterance, whose streamed read stops
-        // at key 0 while its cache stays append-only); the barrier below (a workgroup-scope fence for global memory)
-        // orders the append before the streamed read of that row, which sits in the last tile of the stream.
-        float* qs = reinterpret_cast<float*>(pages + a.pool.max_blocks);          // [64]
-        if (w < 3) {
-            const float* sp = a.lnfix_stat + ((size_t)(b >> 5) * a.lnfix_blocks * 32 + (b & 31)) * 2;
-            float st_s = 0.f, st_q = 0.f;
-            for (int nbk = lane; nbk < a.lnfix_blocks; nbk += 64) {
-                st_s += sp[(size_t)nbk * 64];
-                st_q += sp[(size_t)nbk * 64 + 1];
-            }
-            const float Kf = (float)(a.lnfix_blocks * 16);
-            const float mean = wave_sum(st_s) / Kf;
-            const float var = fmaxf(wave_sum(st_q) / Kf - mean * mean, 0.f);
-            const float rstd = 1.0f / sqrtf(var + a.lnfix_eps);
-            const int n = w * a.D + h * PTTS_HEAD_DIM + lane;
-            const float y = rstd * (a.q[(size_t)b * a.ldq + n] - mean * a.lnfix_c1[n]) + a.lnfix_c2[n];
-            if (w == 0) qs[lane] = y * a.lnfix_scale;
-            else {
-                elem_t* dst = const_cast<elem_t*>(pool) + a.pool.elem_off(b, a.layer, w - 1, h, pos_append) + lane;
-                *dst = to_elem<P>(y);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) q[j] = qs[c * EPL + j];
-    } else {
-        if (!ident) __syncthreads();          // the page ids are in LDS (q was requested at kernel entry)
-    }
-    const int ntiles = (S + TPW - 1) / TPW;
-
-    // one burst = UNR tiles of 1 KiB, all issued before the first use (plain loads: hipcc counts them)
-    auto load_burst = [&](raw_t (&buf)[UNR], int t0, size_t kv_add) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            int tok = (t0 + u * NWAVES) * TPW + tt;
-            if (tok > S - 1) tok = S - 1;
-            const int pg = ident ? page0 + (tok >> 6) : pages[tok >> 6];
-            const raw_t* src = reinterpret_cast<const raw_t*>(pool + (size_t)pg * page_elems + head_off + kv_add +
-                                                              (size_t)(tok & 63) * PTTS_HEAD_DIM);
-            // the cache is read exactly once per step: non-temporal loads keep 170 MB per launch from sweeping the L2s
-            // (measured 34.4 -> 31.3 us per launch, decode pass -7 %)
-            buf[u] = __builtin_nontemporal_load(src);
-        }
-    };
-    auto score_burst = [&](const raw_t (&buf)[UNR], int t0) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int tok = (t0 + u * NWAVES) * TPW + tt;
-            float kf[EPL];
-            L::unpack(buf[u], kf);
-            float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) d = fmaf(q[j], kf[j], d);
-            d = (LPT == 8) ? sum_oct(d) : sum_row16(d);   // lanes of one token row (DPP, no LDS crossbar)
-            if (c == 0 && tok < S) sc[tok] = bias ? d + bias[tok] : d;
-        }
-    };
-
-    // ---------------- pass 1: scores, bursts double-buffered in registers ----------------
-    {
-        int t0 = w;
-        if (!early) load_burst(bufA, t0, 0);
-#ifdef PTTS_STAMPS
-#ifdef PTTS_STAMPS_ATTN_PROLOGUE
-        stv[5] = stamp_cycles();   // pass 1 starts
-#else
-        stv[2] = stamp_cycles();
-#endif
-#endif
-        while (true) {
-            bool more = t0 + STRIDE < ntiles;
-            if (more) load_burst(bufB, t0 + STRIDE, 0);
-            score_burst(bufA, t0);
-            if (!more) break;
-            t0 += STRIDE;
-            more = t0 + STRIDE < ntiles;
-            if (more) load_burst(bufA, t0 + STRIDE, 0);
-            score_burst(bufB, t0);
-            if (!more) break;
-            t0 += STRIDE;
-        }
-    }
-    // first V burst goes out now: it does not depend on the probabilities and flies under the softmax
-    load_burst(bufA, w, v_off);
-    __syncthreads();
-#ifdef PTTS_STAMPS
-#ifdef PTTS_STAMPS_ATTN_PROLOGUE
-    stv[6] = stamp_cycles();       // scores done
-#else
-    stv[3] = stamp_cycles();
-#endif
-#endif
-
-    // ---------------- softmax over [0, S) ----------------
-    float m = -INFINITY;
-    for (int t = tid; t < S; t += NWAVES * 64) m = fmaxf(m, sc[t]);
-    m = wave_max(m);
-    if (lane == 0) wred[w] = m;
-    __syncthreads();
-    m = wred[0];
-#pragma unroll
-    for (int i = 1; i < NWAVES; ++i) m = fmaxf(m, wred[i]);
-    __syncthreads();
-    float sum = 0.f;
-    for (int t = tid; t < S; t += NWAVES * 64) {
-        float e = expf(sc[t] - m);
-        sc[t] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) wred[w] = sum;
-    __syncthreads();
-    sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < NWAVES; ++i) sum += wred[i];
-    for (int t = tid; t < S; t += NWAVES * 64) sc[t] = sc[t] / sum;
-    __syncthreads();
-#if defined(PTTS_STAMPS) && !defined(PTTS_STAMPS_ATTN_PROLOGUE)
-    stv[4] = stamp_cycles();
-#endif
-
-    // ---------------- pass 2: o = P.V ----------------
-    float acc[EPL];
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
-    auto pv_burst = [&](const raw_t (&buf)[UNR], int t0) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int tok = (t0 + u * NWAVES) * TPW + tt;
-            const float p = (tok < S) ? sc[tok] : 0.f;
-            float vf[EPL];
-            L::unpack(buf[u], vf);
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
-        }
-    };
-    {
-        int t0 = w;
-        while (true) {
-            bool more = t0 + STRIDE < ntiles;
-            if (more) load_burst(bufB, t0 + STRIDE, v_off);
-            pv_burst(bufA, t0);
-            if (!more) break;
-            t0 += STRIDE;
-            more = t0 + STRIDE < ntiles;
-            if (more) load_burst(bufA, t0 + STRIDE, v_off);
-            pv_burst(bufB, t0);
-            if (!more) break;
-            t0 += STRIDE;
-        }
-    }
-    // lanes with equal c hold partial sums for the same 16-byte chunk: fold the token-lanes
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        if (LPT == 8) acc[j] += dpp_f<0x128>(acc[j]);   // row_ror:8 pairs lane i with i^8 inside a 16-lane row
-        acc[j] += __shfl_xor(acc[j], 16);
-        acc[j] += __shfl_xor(acc[j], 32);
-    }
-    if (tt == 0) {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) red[w * 64 + c * EPL + j] = acc[j];
-    }
-#if defined(PTTS_STAMPS) && !defined(PTTS_STAMPS_ATTN_PROLOGUE)
-    stv[5] = stamp_cycles();
-#endif
-    __syncthreads();
-    if (tid < PTTS_HEAD_DIM) {
-        float o = 0.f;
-#pragma unroll
-        for (int i = 0; i < NWAVES; ++i) o += red[i * 64 + tid];
-        typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(b >> 5) * 32 * a.D;
-        of[frag_off<OP>(b & 31, h * PTTS_HEAD_DIM + tid)] = to_elem<OP>(o);
-    }
-#ifdef PTTS_STAMPS
-#ifndef PTTS_STAMPS_ATTN_PROLOGUE
-    stv[6] = stamp_cycles();
-#endif
-    stv[7] = stamp_realtime();
-    stamp_store(stref, stv);
-#endif
-}
+#define PTTS_ATTN_SIGNATURE __global__ __launch_bounds__(NWAVES * 64) void attn_decode_kernel(AttnArgs a)
+#define PTTS_ATTN_H blockIdx.x
+#define PTTS_ATTN_B blockIdx.y
+#include "attn_device.inc"
 
 // ------------------------------------------------------------------------------------------------
 // Single-page variant (S <= 64 keys known on the host: cross-attention over a short description).

@@ -32,597 +32,11 @@
 #include <cstdlib>
 
 namespace {
+#define PTTS_GEMM_SIGNATURE __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a)
+#define PTTS_GEMM_BX blockIdx.x
+#define PTTS_GEMM_BY blockIdx.y
+#include "gemm_device.inc"
 
-constexpr int U_MAX = 8;  // weight tiles in flight per wave (per burst)
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-__device__ inline float act_apply(int act, float x) {
-    if (act == ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-    if (act == ACT_GELU_NEW) {
-        return 0.5f * x * (1.0f + tanhf(0.79788456080286535588f * (x + 0.044715f * (x * x * x))));
-    }
-    if (act == ACT_RELU) return fmaxf(x, 0.0f);
-    return x;
-}
-
-template <typename P> struct Tile;
-template <> struct Tile<PBF16> {
-    typedef bf16x8 wfrag;  // 8 bf16 per lane
-    static __device__ inline wfrag load_global(const uint16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
-    // weights are read exactly once per step: non-temporal loads keep them from displacing reusable lines
-    static __device__ inline wfrag load_weights(const uint16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
-    static __device__ inline void mma(const wfrag& a, const wfrag& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    }
-    // B fragment from the padded row-major LDS image: 8 consecutive k of row r
-    static __device__ inline wfrag load_lds(const uint16_t* xs, int ld, int r, int ks_local, int lane) {
-        return *reinterpret_cast<const bf16x8*>(xs + (size_t)r * ld + ks_local * 32 + 8 * (lane >> 4));
-    }
-    // per-lane sum and sum of squares of the 8 values of a fragment (fp32)
-    static __device__ inline void stats(const wfrag& b, float& sum, float& sq) {
-        const u32x4 r = __builtin_bit_cast(u32x4, b);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float lo = __builtin_bit_cast(float, r[i] << 16), hi = __builtin_bit_cast(float, r[i] & 0xffff0000u);
-            sum += lo; sum += hi;
-            sq = fmaf(lo, lo, sq); sq = fmaf(hi, hi, sq);
-        }
-    }
-};
-template <> struct Tile<PF32> {
-    typedef f32x4 wfrag;
-    static __device__ inline wfrag load_global(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-    static __device__ inline wfrag load_weights(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
-    static __device__ inline void mma(const wfrag& a, const wfrag& b, f32x4& c) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[m], c, 0, 0, 0);
-    }
-    static __device__ inline wfrag load_lds(const float* xs, int ld, int r, int ks_local, int lane) {
-        const float* p = xs + (size_t)r * ld + ks_local * 16 + (lane >> 4);
-        f32x4 v;
-        v[0] = p[0]; v[1] = p[4]; v[2] = p[8]; v[3] = p[12];
-        return v;
-    }
-    static __device__ inline void stats(const wfrag& b, float& sum, float& sq) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const float v = b[i]; sum += v; sq = fmaf(v, v, sq); }
-    }
-};
-
-// four consecutive features n .. n+3 (n % 4 == 0) of one row in the fragment image: in the bf16 layout they are 8 contiguous
-// bytes (k & 7 runs over a 4-aligned quad), so ONE 8-byte store replaces four 2-byte stores; the fp32 layout interleaves
-// k & 3 across 16-lane groups (64 elements apart)
-template <typename P>
-__device__ inline void store_frag4(typename P::elem_t* of, int r32, int n, const float (&y)[4]);
-template <>
-__device__ inline void store_frag4<PBF16>(uint16_t* of, int r32, int n, const float (&y)[4]) {
-    uint2 pk;
-    pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{y[0], y[1]}, bf16x2));
-    pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{y[2], y[3]}, bf16x2));
-    *reinterpret_cast<uint2*>(of + frag_off<PBF16>(r32, n)) = pk;
-}
-template <>
-__device__ inline void store_frag4<PF32>(float* of, int r32, int n, const float (&y)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) of[frag_off<PF32>(r32, n + r)] = y[r];
-}
-
-// EPI_T / ACT_T >= 0: the epilogue (activation) is fixed at compile time.  The decode step's six projections run on instances
-// specialised this way: the generic instance carries every epilogue and activation behind run-time switches - 1900 of its 3300
-// instructions, 120 branches - and a launch that executes one path of it jumps across a 12 KB region of code that is cold in
-// the instruction cache at every launch (round-3 stamps: ~2200 cycles between the hand-over barrier and the last store).
-template <typename P, int EPI_T = -1, int ACT_T = -1>
-__device__ inline void epilogue(const GemmArgs& a, int epi, int row, int n, f32x4 v, f32x4 v1, const float4& xres, bool have_res) {
-    // row: absolute output row; n: first of this lane's 4 consecutive output features
-    typedef typename P::elem_t elem_t;
-    const int act = ACT_T >= 0 ? ACT_T : a.act;
-    switch (epi) {
-        case EPI_ROWMAJOR: {
-            float* o = a.out + (size_t)row * a.ldo + n;
-            float s = a.rowmask ? (float)a.rowmask[row] : 1.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (n + r >= a.N) break;
-                float y = v[r];
-                if (a.bias) y += a.bias[n + r];
-                y = act_apply(act, y);
-                if (a.rowmask) y *= s;
-                o[r] = y;
-            }
-            break;
-        }
-        case EPI_RESIDUAL: {
-            float4* o = reinterpret_cast<float4*>(a.out + (size_t)row * a.ldo + n);
-            float4 x = have_res ? xres : *o;     // the residual slice was requested at kernel entry
-            x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
-            *o = x;
-            if (a.xfrag_out) {   // the next LayerNorm-folded projection reads the raw rows as B fragments
-                elem_t* of = reinterpret_cast<elem_t*>(a.xfrag_out) + (size_t)(row >> 5) * 32 * a.ldo;
-                const float xv[4] = {x.x, x.y, x.z, x.w};
-                store_frag4<P>(of, row & 31, n, xv);
-            }
-            break;
-        }
-        case EPI_Q_SCALE: {
-            float4* o = reinterpret_cast<float4*>(a.out + (size_t)row * a.ldo + n);
-            *o = make_float4(v[0] * a.scale, v[1] * a.scale, v[2] * a.scale, v[3] * a.scale);
-            break;
-        }
-        case EPI_ACT_FRAG:
-        case EPI_GATED_FRAG: {
-            elem_t* of = reinterpret_cast<elem_t*>(a.ofrag) + (size_t)(row >> 5) * 32 * a.ldo;
-            float yv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float y = act_apply(act, v[r]);
-                if (epi == EPI_GATED_FRAG) y *= v1[r];
-                yv[r] = y;
-            }
-            store_frag4<P>(of, row & 31, n, yv);
-            break;
-        }
-        case EPI_QKV_SELF:
-        case EPI_KV_CROSS: {
-            // n in [0, nseg*D): segment 0 of QKV_SELF is q (scaled, row-major); the rest go to the cache
-            int seg = n / a.D, nn = n - seg * a.D;
-            int kv = seg;
-            if (epi == EPI_QKV_SELF) {
-                if (seg == 0) {
-                    float4* o = reinterpret_cast<float4*>(a.out + (size_t)row * a.ldo + nn);
-                    *o = make_float4(v[0] * a.scale, v[1] * a.scale, v[2] * a.scale, v[3] * a.scale);
-                    break;
-                }
-                kv = seg - 1;
-                if (a.rope_k && seg == 1) {      // rotary variant: k leaves in fp32 next to q, the rope kernel appends it
-                    float4* o = reinterpret_cast<float4*>(a.out + (size_t)row * a.ldo + a.D + nn);
-                    *o = make_float4(v[0], v[1], v[2], v[3]);
-                    break;
-                }
-            }
-            int b, tok;
-            if (epi == EPI_QKV_SELF) {
-                if (a.npos > 0) { b = row / a.npos; tok = a.pos0 + (row - b * a.npos); }
-                else { b = row; tok = scalar_load_int(&a.state->pos); }     // scalar cache: no wait on the vector-memory queue (invariant: no gemm launch writes StepState)
-            } else { b = row / a.T; tok = row - b * a.T; }
-            elem_t* c = reinterpret_cast<elem_t*>(a.pool.base) +
-                        a.pool.elem_off(b, a.layer, kv, nn >> 6, tok) + (nn & 63);
-            // the lane's four consecutive features are contiguous in the cache row: ONE 8-byte (bf16) / 16-byte (fp32) store
-            if (P::IS_BF16) {
-                uint2 pk;
-                pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{v[0], v[1]}, bf16x2));
-                pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{v[2], v[3]}, bf16x2));
-                *reinterpret_cast<uint2*>(c) = pk;
-            } else {
-                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            break;
-        }
-    }
-}
-
-template <typename P, int NW, int NB, bool STAGE, int KI, int H2, bool FOLD, int EPI_T = -1, int ACT_T = -1, int W2_T = -1, int TILES_T = 0,
-          bool QR = false>
-__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
-    // QR (H2 = 1, no fold, no second role): one 8-ROW QUARTER of the m-tile per workgroup instead of a 16-row half.  The
-    // residual projections with N = 1024 have 64 feature blocks: 128 half-workgroups leave half of the 256 CUs idle while each
-    // busy CU pulls 256 KB (fc2) through its 64 B / clock load path - the stamps' longest phase.  Quarters put 256 workgroups
-    // on the chip (192 KB each for fc2).  The MFMA still multiplies 16 activation columns: lanes 8 .. 15 of each 16-lane group
-    // load the rows of lanes 0 .. 7 again, their (duplicate) results are dropped - every kept element is the same dot product
-    // in the same order as on the half-split grid (bit-identical).
-    static_assert(!QR || (H2 == 1 && !FOLD && !STAGE && W2_T == 0 && NB == 1), "quarter-row workgroups: plain residual projections only");
-    // EPI_T / ACT_T: see epilogue().  W2_T = 0: the launch has no second role (the look-ahead code is compiled out).
-    // TILES_T > 0 (fragment input): K / KSTEP == NW * TILES_T exactly - every wave streams TILES_T tiles in ONE burst with no
-    // per-tile guard, so the tile addresses are a compile-time stride apart (the guarded form recomputes each address with a
-    // multiply chain: ~450 scalar / vector instructions in front of the first load, in-kernel stamps: ~1 us of the launch).
-    constexpr int U = TILES_T > 0 ? TILES_T : U_MAX;
-    // (Pulling every kernel-argument field into SGPRs with one batched fetch at entry - an empty asm with "s" operands - was
-    // measured on these instances: decode pass 3722 -> 3779 ms, i.e. slower; hipcc's piecemeal fetches overlap with the first loads.)
-    // FOLD (fragment input, NB = 1): the fragments are the raw residual rows and W carries the LayerNorm gain.
-    // Row statistics (sum x, sum x^2 over the bf16/fp32 values the MFMA consumes) are accumulated per lane on the
-    // VALU from the B fragments while the weight tiles are still in flight, folded across the four k-groups of a
-    // row with two shuffles and across waves through LDS.  (A first version took them from the matrix cores -
-    // ones . x and the diagonal of x . x^T; with two processes sharing the GPU those values were occasionally
-    // wrong, about once in 3e4 launches, while the main products never were; see DESIGN_HISTORY.md section A.)
-    // H2 = 2: the workgroup covers both 16-row halves of the m-tile.  H2 = 1 (fragment input only): one half per
-    // workgroup; the two halves of a feature block sit 8 apart in the linear block id, i.e. on the same XCD, so
-    // the second read of the block's weights is served by that XCD's L2.
-    // KI: float4 per lane per activation row held in registers by the staged prologue (K chunk <= 256*KI)
-    typedef typename P::elem_t elem_t;
-    typedef Tile<P> T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef PTTS_STAMPS
-    // 0 realtime at entry, 1 cycles at entry, 2 every global load of the first burst issued (kernel arguments arrived, addresses
-    // computed), 3 every load of the burst landed (diagnostic-only vmcnt(0)), 4 MFMA loop done, 5 K-split hand-over + barrier
-    // done, 6 epilogue stores issued, 7 realtime at exit
-    unsigned long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const StampRef stref = a.stamps;
-    stv[0] = stamp_realtime();
-    stv[1] = stamp_cycles();
-#endif
-    constexpr int KSTEP = P::KSTEP, EPL = P::EPL;
-    constexpr int TILE = 64 * EPL;                       // elements per 1 KiB tile
-    constexpr int KC = 256 * KI;                         // K chunk parked in LDS
-    constexpr int PAD = 16 / (int)sizeof(elem_t);        // 16-byte row pad -> conflict-free b128 reads
-    constexpr int RPW = 32 / NW;                         // activation rows per wave
-    constexpr int RB = RPW < 4 ? RPW : 4;                // rows normalised together (ILP across rows)
-
-    // The wave index is uniform: keep it in an SGPR so every `ks < cend` tile guard below is a scalar branch.
-    // With a VGPR-derived index the compiler implements the guards by EXEC masking and drops the skip-branch
-    // over short blocks - but MFMA ignores EXEC, so an empty tile slot would accumulate unloaded registers.
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int nb0 = blockIdx.x * NB, hsel = 0, rsel = 0;
-    bool role2 = false;
-    if (H2 == 1) {
-        int id = blockIdx.x;
-        const int ids1 = ((a.N / 16 + 7) / 8) * 16;
-        if (W2_T != 0 && !STAGE && !FOLD && a.W2 && id >= ids1) {   // second role: the look-ahead product (uniform per workgroup)
-            role2 = true;
-            id -= ids1;
-            a.W = a.W2; a.N = a.N2; a.K = a.K2;
-            a.epi = EPI_ROWMAJOR; a.out = a.out2; a.ldo = a.ldo2;
-            a.bias = nullptr; a.rowmask = nullptr; a.act = ACT_NONE; a.xfrag_out = nullptr; a.xstat = nullptr;
-        }
-        if (QR) {      // groups of 8 blocks x 4 quarters; the quarters of a block sit 8 apart (same XCD: its L2 serves the re-reads)
-            nb0 = ((id >> 5) << 3) + (id & 7);
-            hsel = (id >> 4) & 1;
-            rsel = (id >> 3) & 1;
-        } else {
-            nb0 = (((id >> 4) << 3) + (id & 7)) * NB;
-            hsel = (id >> 3) & 1;
-        }
-        if (nb0 * 16 >= a.N) return;            // padding blocks of the last group of 8 (no stamp record: zeros)
-    } else if (W2_T != 0 && !STAGE && !FOLD && a.W2) {       // wide second role: 32-row workgroups, the look-ahead blocks follow the first role's
-        const int ids1 = a.N / (16 * NB);
-        if ((int)blockIdx.x >= ids1) {
-            role2 = true;
-            nb0 = ((int)blockIdx.x - ids1) * NB;
-            a.W = a.W2; a.N = a.N2; a.K = a.K2;
-            a.epi = EPI_ROWMAJOR; a.out = a.out2; a.ldo = a.ldo2;
-            a.bias = nullptr; a.rowmask = nullptr; a.act = ACT_NONE; a.xfrag_out = nullptr; a.xstat = nullptr;
-        }
-    }
-    // this workgroup's epilogue: fixed by the instance, except for the second role's raw row-major product
-    const int epi = EPI_T >= 0 ? (role2 ? (int)EPI_ROWMAJOR : EPI_T) : a.epi;
-    const int m0 = blockIdx.y * 32;
-    const int K = a.K;
-    const int ksteps = K / KSTEP;
-    const elem_t* Wp = reinterpret_cast<const elem_t*>(a.W);
-
-    const int kc = STAGE ? (K < KC ? K : KC) : 0;
-    const int ld = kc + PAD;
-    elem_t* xs = reinterpret_cast<elem_t*>(smem);
-    // K-split partial sums [NW][NB][2][64] float4: reuse the stage image once every wave is done with it
-    float* red = reinterpret_cast<float*>(smem);
-
-    f32x4 acc[NB][2];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) { acc[i][0] = {0, 0, 0, 0}; acc[i][1] = {0, 0, 0, 0}; }
-
-    const bool norm = STAGE && (a.pro == PRO_LAYERNORM || a.pro == PRO_RMSNORM);
-    // residual epilogue: thread t < NB*128 finishes outputs (row, n..n+3); fetch that slice of x now so the
-    // read-modify-write at the end does not start with a cold load
-    float4 xres = make_float4(0, 0, 0, 0);
-    bool have_res = false;
-    if (epi == EPI_RESIDUAL && tid < NB * 64 * H2) {
-        const int ln = tid & 63, hh = H2 == 2 ? ((tid >> 6) & 1) : hsel, ii = H2 == 2 ? (tid >> 7) : (tid >> 6);
-        const int row = m0 + 16 * hh + (QR ? 8 * rsel + (ln & 7) : (ln & 15)), n = (nb0 + ii) * 16 + 4 * (ln >> 4);
-        if (row < a.M && n < a.N && (!QR || (ln & 8) == 0)) {
-            xres = *reinterpret_cast<const float4*>(a.out + (size_t)row * a.ldo + n);
-            have_res = true;
-        }
-    }
-    // FOLD with NB > 1 (LM heads: three feature blocks per workgroup, 204 workgroups instead of 612 whose starts spread over
-    // 6.6 us of the launch - round-3 stamps, slot 168): thread t finishes item t (feature block i = t / (64 H2)), so it holds
-    // that block's fold constants; one item per thread
-    static_assert(!FOLD || NB * 64 * H2 <= NW * 64, "folded epilogue: one item per thread");
-    float4 c1v = make_float4(0, 0, 0, 0), c2v = make_float4(0, 0, 0, 0);
-    if (FOLD && tid < NB * 64 * H2) {
-        const int n = (nb0 + (H2 == 2 ? (tid >> 7) : (tid >> 6))) * 16 + 4 * ((tid & 63) >> 4);
-        if (n < a.N) {
-            c1v = *reinterpret_cast<const float4*>(a.c1 + n);
-            c2v = *reinterpret_cast<const float4*>(a.c2 + n);
-        }
-    }
-    float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};
-    // bf16 folded path: the row statistics come from the matrix cores - ones . x (every output row = the column sums) and
-    // x . x^T (its diagonal = the sums of squares), two MFMAs per fragment instead of ~100 cycles of VALU unpack / add / fma
-    // per fragment (round-3 stamps: the folded instances' MFMA phase was 860-1000 cycles against 200-350 on the plain ones).
-    // The activation fragment serves as BOTH operands of the second product: A- and B-fragment layouts hold element
-    // (row l & 15, k = 8 (l >> 4) + j) in the same lane and slot.  (Round 1's first statistics also came from MFMAs and were
-    // blamed for a rare wrong value; the cause was the inline-asm hand-over store behind the last MFMA, fixed in round 2.)
-    constexpr bool MSTAT = FOLD && P::IS_BF16;
-    f32x4 ms_sum[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, ms_sq[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    typename T::wfrag ones_frag;
-    if (MSTAT) {
-        const u32x4 o = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};       // eight bf16 1.0
-        ones_frag = __builtin_bit_cast(typename T::wfrag, o);
-    }
-    const int cstep = STAGE ? KC / KSTEP : ksteps;   // only the LDS-staged path needs K chunks
-
-    // first burst of this wave's weight tiles: issued before the prologue so HBM latency hides under it
-    typename T::wfrag wt[U][NB];
-    // fragment input: the activation fragments of the burst travel with it, each in its own registers.  (They used
-    // to be fetched tile by tile inside the MFMA loop: four dependent L2 round trips per launch, and hipcc recycled
-    // the registers of operands whose MFMAs were still queued - with two processes sharing the GPU the folded
-    // H2 = 2 instance, six MFMAs per tile, then produced a wrong output feature about once in 2000 launches.)
-    typename T::wfrag bt[STAGE ? 1 : U][STAGE ? 1 : H2];
-    auto load_burst = [&](int ks0, int cend) {
-        if (!STAGE) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int ks = ks0 + u * NW;
-                if (TILES_T > 0 || ks < cend) {
-                    // the second role reads its first ksplit k-steps from xfrag_lo, the rest from xfrag
-                    const bool lo = role2 && ks < a.ksplit;
-                    const int kk = role2 && !lo ? ks - a.ksplit : ks;
-                    const int ksrc = !role2 ? K : (lo ? a.ksplit * KSTEP : K - a.ksplit * KSTEP);
-                    const elem_t* xf = reinterpret_cast<const elem_t*>(lo ? a.xfrag_lo : a.xfrag) + (size_t)blockIdx.y * 32 * ksrc +
-                                       (size_t)(kk * 2 + hsel) * TILE + (QR ? ((lane & 0x30) | (8 * rsel + (lane & 7))) : lane) * EPL;
-                    bt[STAGE ? 0 : u][0] = T::load_global(xf);
-                    if (H2 == 2) bt[STAGE ? 0 : u][STAGE ? 0 : H2 - 1] = T::load_global(xf + TILE);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ks = ks0 + u * NW;
-            if (TILES_T > 0 || ks < cend) {
-#pragma unroll
-                for (int i = 0; i < NB; ++i)
-                    wt[u][i] = T::load_weights(Wp + ((size_t)(nb0 + i) * ksteps + ks) * TILE + lane * EPL);
-            }
-        }
-    };
-    // Loads return in issue order (vmcnt), so the L2-resident activation rows and the LayerNorm
-    // affine go out FIRST and the HBM weight tiles right behind them: the normalisation then waits
-    // only for what it needs while the weights are still in flight.
-    const int cend0 = cstep < ksteps ? cstep : ksteps;
-    if (!STAGE) load_burst(w, cend0);
-    // (Pulling the epilogue's kernel-argument lines and state->pos into SGPRs here, under the tile burst, was measured too:
-    // decode pass 3617 -> 3630 ms.  Like the batch at kernel entry it loses; hipcc's own placement stays.)
-#ifdef PTTS_STAMPS
-    stv[2] = stamp_cycles();
-    if (!STAGE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stv[3] = stamp_cycles(); }
-#endif
-
-    for (int c0 = 0; c0 < ksteps; c0 += cstep) {
-        const int cend = (c0 + cstep < ksteps) ? c0 + cstep : ksteps;
-        if (STAGE) {
-            // ---- wave per row, RB rows at a time: fp32 rows -> registers, (LN | RMS), convert, park in LDS ----
-            if (c0 > 0) __syncthreads();
-            const int kbase = c0 * KSTEP, klen = (cend - c0) * KSTEP;
-            float4 gam[KI], bet[KI];
-            for (int rb = 0; rb < RPW; rb += RB) {
-                float4 v[RB][KI];
-#pragma unroll
-                for (int j = 0; j < RB; ++j) {
-                    const int row = m0 + w * RPW + rb + j;
-                    const float* xr = a.x + (size_t)(row < a.M ? row : a.M - 1) * a.ldx + kbase;
-#pragma unroll
-                    for (int i = 0; i < KI; ++i) {
-                        const int k = 4 * lane + 256 * i;
-                        v[j][i] = (k < klen) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0, 0, 0, 0);
-                    }
-                }
-                if (rb == 0) {
-#pragma unroll
-                    for (int i = 0; i < KI; ++i) {
-                        const int k = 4 * lane + 256 * i;
-                        gam[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-                        bet[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (norm && k < klen) {
-                            gam[i] = *reinterpret_cast<const float4*>(a.gamma + kbase + k);
-                            if (a.pro == PRO_LAYERNORM) bet[i] = *reinterpret_cast<const float4*>(a.beta + kbase + k);
-                        }
-                    }
-                    if (c0 == 0) load_burst(w, cend0);      // weight tiles queue up behind the rows
-                }
-                // packed fp32 math (v_pk_add/mul/fma_f32 on float2): the prologue is VALU-issue bound because
-                // every workgroup normalises all 32 rows; ~3 wave-instructions per element pair
-                float scale[RB], shift[RB];     // y = (x * scale + shift) * gamma + beta   (ATen's LayerNorm form)
-#pragma unroll
-                for (int j = 0; j < RB; ++j) { scale[j] = 1.f; shift[j] = 0.f; }
-                if (norm) {   // whole row is in this chunk (host guarantees K <= KC for LN/RMS)
-                    const float invK = 1.0f / (float)K;
-                    float mean[RB];
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) mean[j] = 0.f;
-                    if (a.pro == PRO_LAYERNORM) {
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) {
-                            v2f sm = {0.f, 0.f};
-#pragma unroll
-                            for (int i = 0; i < KI; ++i) sm += v2f{v[j][i].x, v[j][i].y} + v2f{v[j][i].z, v[j][i].w};
-                            mean[j] = wave_sum(sm[0] + sm[1]) * invK;
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) {
-                        v2f q = {0.f, 0.f};
-                        const v2f mm = {mean[j], mean[j]};
-#pragma unroll
-                        for (int i = 0; i < KI; ++i) {
-                            if (4 * lane + 256 * i < klen) {
-                                const v2f d0 = v2f{v[j][i].x, v[j][i].y} - mm, d1 = v2f{v[j][i].z, v[j][i].w} - mm;
-                                q = d0 * d0 + q;
-                                q = d1 * d1 + q;
-                            }
-                        }
-                        const float rstd = 1.0f / sqrtf(wave_sum(q[0] + q[1]) * invK + a.eps);
-                        scale[j] = rstd;
-                        shift[j] = -rstd * mean[j];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < KI; ++i) {
-                    const int k = 4 * lane + 256 * i;
-                    if (k < klen) {
-                        const v2f g0 = {gam[i].x, gam[i].y}, g1 = {gam[i].z, gam[i].w};
-                        const v2f b0 = {bet[i].x, bet[i].y}, b1 = {bet[i].z, bet[i].w};
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) {
-                            v2f y0 = {v[j][i].x, v[j][i].y}, y1 = {v[j][i].z, v[j][i].w};
-                            if (norm) {
-                                const v2f sc = {scale[j], scale[j]}, sh = {shift[j], shift[j]};
-                                if (a.pro == PRO_LAYERNORM) {
-                                    y0 = (y0 * sc + sh) * g0 + b0;
-                                    y1 = (y1 * sc + sh) * g1 + b1;
-                                } else {   // T5 RMSNorm: w * (x * rsqrt(mean(x^2) + eps))
-                                    y0 = g0 * (y0 * sc);
-                                    y1 = g1 * (y1 * sc);
-                                }
-                            }
-                            elem_t* dst = xs + (size_t)(w * RPW + rb + j) * ld + k;
-                            if (P::IS_BF16) {
-                                uint2 pk;   // one v_cvt_pk_bf16_f32 per pair
-                                pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(y0, bf16x2));
-                                pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(y1, bf16x2));
-                                *reinterpret_cast<uint2*>(dst) = pk;
-                            } else {
-                                lds_store_b128(dst, f32x4{y0[0], y0[1], y1[0], y1[1]});
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        // ---- stream this wave's weight tiles of the chunk ----
-        for (int ks0 = c0 + w; ks0 < cend; ks0 += NW * U) {
-            if (ks0 != w) load_burst(ks0, cend);      // the first burst is already in flight
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int ks = ks0 + u * NW;
-                if (TILES_T > 0 || ks < cend) {
-                    typename T::wfrag b0, b1;
-                    if (STAGE) {
-                        b0 = T::load_lds(xs, ld, (lane & 15), ks - c0, lane);
-                        b1 = T::load_lds(xs, ld, 16 + (lane & 15), ks - c0, lane);
-                    } else {
-                        b0 = bt[STAGE ? 0 : u][0];
-                        if (H2 == 2) b1 = bt[STAGE ? 0 : u][STAGE ? 0 : H2 - 1];
-                    }
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        T::mma(wt[u][i], b0, acc[i][0]);
-                        if (H2 == 2) T::mma(wt[u][i], b1, acc[i][1]);
-                    }
-                    if (MSTAT) {
-                        T::mma(ones_frag, b0, ms_sum[0]);
-                        T::mma(b0, b0, ms_sq[0]);
-                        if (H2 == 2) { T::mma(ones_frag, b1, ms_sum[1]); T::mma(b1, b1, ms_sq[1]); }
-                    } else if (FOLD) {
-                        T::stats(b0, st_sum[0], st_sq[0]);
-                        if (H2 == 2) T::stats(b1, st_sum[1], st_sq[1]);
-                    }
-                }
-            }
-        }
-    }
-
-#ifdef PTTS_STAMPS
-    stv[4] = stamp_cycles();
-#endif
-    // ---- K-split reduction in fixed wave order, then the fused epilogue ----
-    f32x4* redv = reinterpret_cast<f32x4*>(red);
-    if (STAGE) __syncthreads();   // all B-fragment reads of the stage image have retired
-    // hand-over through LDS: plain stores, so hipcc pads the MFMA -> ds_write hazard (ptts_common.h)
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        lds_store_b128(&redv[((w * NB + i) * 2 + 0) * 64 + lane], acc[i][0]);
-        if (H2 == 2) lds_store_b128(&redv[((w * NB + i) * 2 + 1) * 64 + lane], acc[i][1]);
-    }
-    // per wave and 16-row half: sum(x) and sum(x^2) of its k-steps for the 16 rows (lanes l, l+16, l+32, l+48 hold
-    // the four k-groups of row l & 15)
-    float* stat = red + (size_t)NW * NB * 2 * 64 * 4;    // [NW][2 halves][2][16]
-    if (FOLD) {
-#pragma unroll
-        for (int h = 0; h < H2; ++h) {
-            if (MSTAT) {
-                // ones . x: every accumulator row holds the column sums, lane l < 16 has activation row l in slot 0;
-                // x . x^T: element (i, i) sits in lane 16 (i >> 2) + i, slot i & 3
-                if (lane < 16) lds_store_b32(&stat[((w * 2 + h) * 2 + 0) * 16 + lane], ms_sum[h][0]);
-                if ((lane >> 4) == ((lane & 15) >> 2)) {
-                    const f32x4 q4 = ms_sq[h];
-                    const int m = lane & 3;
-                    lds_store_b32(&stat[((w * 2 + h) * 2 + 1) * 16 + (lane & 15)], m == 0 ? q4[0] : (m == 1 ? q4[1] : (m == 2 ? q4[2] : q4[3])));
-                }
-                continue;
-            }
-            float sv = st_sum[h], qv = st_sq[h];
-            sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
-            sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
-            if (lane < 16) {
-                lds_store_b32(&stat[((w * 2 + h) * 2 + 0) * 16 + lane], sv);
-                lds_store_b32(&stat[((w * 2 + h) * 2 + 1) * 16 + lane], qv);
-            }
-        }
-    }
-    __syncthreads();
-#ifdef PTTS_STAMPS
-    stv[5] = stamp_cycles();
-#endif
-    const bool gated = (epi == EPI_GATED_FRAG);
-    const int items = gated ? 128 : NB * 64 * H2;
-    for (int t = tid; t < items; t += NW * 64) {
-        const int ln = t & 63, h = H2 == 2 ? ((t >> 6) & 1) : 0, i = gated ? 0 : (H2 == 2 ? (t >> 7) : (t >> 6));
-        f32x4 s = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-        for (int ww = 0; ww < NW; ++ww) {
-            f32x4 p = redv[((ww * NB + i) * 2 + h) * 64 + ln];
-            s += p;
-            if (gated) s1 += redv[((ww * NB + 1) * 2 + h) * 64 + ln];
-        }
-        const int row = m0 + 16 * (H2 == 2 ? h : hsel) + (QR ? 8 * rsel + (ln & 7) : (ln & 15));
-        const bool lane_ok = !QR || (ln & 8) == 0;          // quarter rows: lanes 8 .. 15 of a group hold duplicates
-        if (FOLD) {
-            float sx = 0.f, sq = 0.f;
-            for (int ww = 0; ww < NW; ++ww) {
-                sx += stat[((ww * 2 + h) * 2 + 0) * 16 + (ln & 15)];
-                sq += stat[((ww * 2 + h) * 2 + 1) * 16 + (ln & 15)];
-            }
-            const float invK = 1.0f / (float)K;
-            const float mean = a.rms ? 0.f : sx * invK;          // RMSNorm variant: no centring
-            const float var = a.rms ? sq * invK : fmaxf(sq * invK - mean * mean, 0.f);
-            const float rstd = 1.0f / sqrtf(var + a.eps);
-            s[0] = rstd * (s[0] - mean * c1v.x) + c2v.x;
-            s[1] = rstd * (s[1] - mean * c1v.y) + c2v.y;
-            s[2] = rstd * (s[2] - mean * c1v.z) + c2v.z;
-            s[3] = rstd * (s[3] - mean * c1v.w) + c2v.w;
-        }
-        const int n = gated ? blockIdx.x * 16 + 4 * (ln >> 4) : (nb0 + i) * 16 + 4 * (ln >> 4);
-        if (row < a.M && lane_ok) {
-            if (EPI_T >= 0 && role2) epilogue<P, EPI_ROWMAJOR, ACT_NONE>(a, EPI_ROWMAJOR, row, n, s, s1, xres, false);
-            else epilogue<P, EPI_T, ACT_T>(a, epi, row, n, s, s1, xres, have_res && t == tid);
-        }
-        if (!STAGE && !FOLD && a.xstat && epi == EPI_RESIDUAL) {
-            // partial LayerNorm statistics of the rows just written, over this block's 16 columns, on the values the
-            // weight dtype will hold (so that a consumer's mean subtraction matches what its MFMA multiplied)
-            float ps = 0.f, pq = 0.f;
-            if (row < a.M && have_res) {
-                const float xv[4] = {xres.x + s[0], xres.y + s[1], xres.z + s[2], xres.w + s[3]};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = from_elem<P>(to_elem<P>(xv[r]));
-                    ps += v;
-                    pq = fmaf(v, v, pq);
-                }
-            }
-            ps += __shfl_xor(ps, 16); pq += __shfl_xor(pq, 16);
-            ps += __shfl_xor(ps, 32); pq += __shfl_xor(pq, 32);
-            if (ln < (QR ? 8 : 16) && row < a.M) {
-                float* st2 = a.xstat + (((size_t)blockIdx.y * (a.N / 16) + nb0 + i) * 32 + 16 * (H2 == 2 ? h : hsel) + 8 * rsel + ln) * 2;
-                st2[0] = ps;
-                st2[1] = pq;
-            }
-        }
-    }
-#ifdef PTTS_STAMPS
-    stv[6] = stamp_cycles();
-    stv[7] = stamp_realtime();
-    stamp_store(stref, stv);
-#endif
-}
 
 template <typename P, int NW, int NB, bool STAGE, int KI, int H2 = 2, bool FOLD = false, int EPI_T = -1, int ACT_T = -1, int W2_T = -1, int TILES_T = 0,
           bool QR = false>

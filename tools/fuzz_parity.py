@@ -105,7 +105,23 @@ def generate_case(case):
             benign += 1
         else:
             bad = (b, c, m)
-    ok = bad is None and (benign > 0 or (got.shape == want.shape and bool(torch.equal(got, want))))
+    # Verdict.  No utterance may differ on a clear margin.  Without a benign divergence the two id matrices must be
+    # EQUAL, shape included.  With one, the other utterances were already compared over the common columns above (no entry in
+    # `diverged`), and a length difference must be explainable by the diverged utterance alone: a run ends when EVERY row has
+    # finished, so an utterance with identical ids in both runs had finished by the shorter run's last column and the longer
+    # run may only hold pad for it beyond that column.
+    diverged = set()
+    for b in range(B):
+        if bool((got[b * K:(b + 1) * K, :n] != want[b * K:(b + 1) * K, :n]).any()):
+            diverged.add(b)
+    tail_ok = True
+    longer = got if got.shape[1] > want.shape[1] else want
+    if longer.shape[1] > n:
+        for b in range(B):
+            if b not in diverged and bool((longer[b * K:(b + 1) * K, n:] != cfg.decoder.pad_token_id).any()):
+                tail_ok = False
+                bad = bad or (b, n, float("nan"))
+    ok = bad is None and tail_ok and (benign > 0 or (got.shape == want.shape and bool(torch.equal(got, want))))
     print(f"{'ok  ' if ok else 'FAIL'} {tag}: columns {tuple(got.shape)} vs {tuple(want.shape)}, utterances that left on a sub-1e-3 margin {benign}"
           + ("" if bad is None else f", utterance {bad[0]} differs at column {bad[1]} where the oracle's margin is {bad[2]:.2e}"), flush=True)
     del model
