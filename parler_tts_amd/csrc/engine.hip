@@ -18,6 +18,7 @@
 #include "../../include/parler_tts_hip.h"
 #include "attn.h"
 #include "conv.h"
+#include "fused.h"
 #include "gemm.h"
 #include "misc.h"
 
@@ -159,6 +160,11 @@ struct ptts_engine {
     const long long* force_seq = nullptr;   // ptts_set_forced_sequence
     long long* own_choice = nullptr;
     StepState* state = nullptr;
+    // fused QKV + self-attention launch (fused.hip): arrival tags [layers][m-tiles][heads][32] + an error word (bounded spins)
+    int* fuse_arrive = nullptr;
+    int* fuse_err = nullptr;
+    size_t fuse_arrive_ints = 0;
+    bool fuse_qkv_attn = true;          // PTTS_NO_FUSED_QKV_ATTN=1 (read per launch in fused.hip too): the two launches of rounds 1-4
     // ptts_state_snapshot / ptts_state_poll: pinned host copies of the loop state, one event per slot
     int* snap_host = nullptr;               // pinned, host-mapped: [PTTS_STATE_SLOTS][8 ints] (6 state fields, pad, sequence stamp)
     int* snap_dev = nullptr;                // the same memory as the device sees it
@@ -399,6 +405,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
         // Look-ahead QKV (layers behind the first): the raw product x.Wqkv'^T was computed by the previous layer's fc2 launch
         // (second role, below); the self-attention kernel finishes the LayerNorm, scales q and appends k / v itself.
         const bool pre_qkv = e->look2_active && l > 0 && npos == 0;
+        bool qkv_built = false;
         if (!pre_qkv) {
             g = GemmArgs();
             g.W = w.qkv.ptr; g.N = 3 * D; g.K = D; g.M = M;
@@ -407,16 +414,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             g.epi = EPI_QKV_SELF; g.out = wk.q; g.ldo = D; g.scale = scale; g.pool = make_pool(e, false); g.layer = l;
             g.state = e->state; g.D = D; g.npos = npos; g.pos0 = pos0;
             if (e->v_rope) { g.rope_k = 1; g.ldo = 2 * D; }      // q | unrotated k leave in fp32, v goes to the cache
-            DBG_GATE(e);
-            STAMP_ARGS(e, g);
-            PTTS_TRY(launch_gemm(e, g, s));
-            if (e->v_rope) {
-                RopeArgs ra;
-                ra.qk = wk.q; ra.ld = 2 * D; ra.D = D; ra.H = c.heads; ra.rows = M; ra.pool = make_pool(e, false); ra.layer = l;
-                ra.state = e->state; ra.npos = npos; ra.pos0 = pos0; ra.cos_t = e->rope_cos; ra.sin_t = e->rope_sin;
-                DBG_GATE(e);
-                HIP_TRY(rope_launch(ra, e->dt, s));
-            }
+            qkv_built = true;
         }
         // self attention over the cached tokens
         AttnArgs a;
@@ -428,14 +426,35 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             a.q = e->qkv_raw; a.ldq = 3 * D; a.lnfix_qkv = 1; a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16;
             a.lnfix_c1 = w.qkv_f.c1; a.lnfix_c2 = w.qkv_f.c2; a.lnfix_eps = 1e-5f; a.lnfix_scale = scale;
         }
+        // ONE launch for the projection and the attention where the pair qualifies (fused.hip): decode passes only, never under
+        // the kernel-by-kernel debug gate (a pass cut short would leave arrival tags without their attention)
+        const bool fuse = qkv_built && npos == 0 && !e->v_rope && e->dbg_stop < 0 && e->fuse_qkv_attn && e->fuse_arrive &&
+                          (size_t)c.layers * ((M + 31) / 32) * c.heads * 32 <= e->fuse_arrive_ints && fused_qkv_attn_supported(g, a, e->dt);
+        if (qkv_built && !fuse) {
+            DBG_GATE(e);
+            STAMP_ARGS(e, g);
+            PTTS_TRY(launch_gemm(e, g, s));
+            if (e->v_rope) {
+                RopeArgs ra;
+                ra.qk = wk.q; ra.ld = 2 * D; ra.D = D; ra.H = c.heads; ra.rows = M; ra.pool = make_pool(e, false); ra.layer = l;
+                ra.state = e->state; ra.npos = npos; ra.pos0 = pos0; ra.cos_t = e->rope_cos; ra.sin_t = e->rope_sin;
+                DBG_GATE(e);
+                HIP_TRY(rope_launch(ra, e->dt, s));
+            }
+        }
         EventPair* ep = nullptr;
         if (profile && e->ev_used < e->ev_pool.size()) {
             ep = &e->ev_pool[e->ev_used++];
             ep->kind = 0;
             ep->bytes = 2.0 * M * (double)(e->host_pos + 1) * D * (double)e->esz;
+            if (fuse) ep->bytes += 3.0 * D * (double)D * (double)e->esz;      // + the QKV weights the same launch streams
         }
         DBG_GATE(e);
-        if (npos > 0) {
+        if (fuse) {
+            int v = gemm_validate(g, e->dt);
+            if (v != 0) return fail(PTTS_E_INVALID, "gemm shape rejected (code %d): M=%d N=%d K=%d pro=%d epi=%d", v, g.M, g.N, g.K, g.pro, g.epi);
+            HIP_TRY(fused_qkv_attn_launch(g, a, M, c.heads, e->dt, e->fuse_arrive, e->fuse_err, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr));
+        } else if (npos > 0) {
             a.npos = npos; a.pos0 = pos0;
             HIP_TRY(attn_causal_launch(a, B_utt, c.heads, e->dt, e->dt, s));
         } else {
@@ -980,6 +999,9 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->unfinished, sizeof(int) * (rows * K + 32));     // + 32: the attention kernel reads 16 flags from an utterance's first one, whatever K is
     A(e->force, sizeof(long long) * rows * K);
     A(e->state, sizeof(StepState));
+    e->fuse_qkv_attn = getenv("PTTS_NO_FUSED_QKV_ATTN") == nullptr;
+    e->fuse_arrive_ints = fused_arrive_ints(cfg->layers, e->mtiles, cfg->heads) + 32;
+    A(e->fuse_arrive, sizeof(int) * e->fuse_arrive_ints);          // the last 32 ints: the error word (own line)
     if (cfg->t5_layers > 0) {
         const int inner = cfg->t5_heads * cfg->t5_dkv;
         const size_t trows = ((size_t)Bm * cfg->max_desc_len + 31) / 32 * 32;
@@ -990,6 +1012,8 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     }
 #undef A
     if (rc != PTTS_OK) { ptts_destroy(e); return rc; }
+    e->fuse_err = e->fuse_arrive + e->fuse_arrive_ints - 32;
+    if (hipMemset(e->fuse_arrive, 0, sizeof(int) * e->fuse_arrive_ints) != hipSuccess) { ptts_destroy(e); return fail(PTTS_E_HIP, "hipMemset failed"); }
     // identity page tables
     std::vector<int> tab(Bm * e->self_blocks);
     for (size_t i = 0; i < tab.size(); ++i) tab[i] = (int)i;
@@ -1232,6 +1256,11 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     e->dbg_count = 0;
     drop_graph(e);
     PTTS_TRY(refresh_folds(e, s));
+    // arrival tags of the fused QKV + attention launches carry pos + 1: a new call restarts pos, so the tags start from zero
+    if (e->fuse_arrive) {
+        HIP_TRY(hipMemsetAsync(e->fuse_arrive, 0, sizeof(int) * e->fuse_arrive_ints, s));
+        e->fuse_err = e->fuse_arrive + e->fuse_arrive_ints - 32;
+    }
     e->B = B; e->B_eff = B_eff; e->T = T; e->P = P; e->L = L;
     // the look-ahead query needs the folded projection, the single-page cross-attention kernel and bf16-size k-steps
     e->look_active = e->lookahead && e->fold_ln && (e->fold_mask & 2) && !e->no_page_kernel && T <= PTTS_PAGE_TOKENS;
@@ -1433,7 +1462,10 @@ int ptts_get_state(ptts_engine* e, ptts_state* out, void* stream) {
     hipStream_t s;
     PTTS_TRY(enter_stream(e, stream, &s));
     HIP_TRY(hipMemcpyAsync(&st, e->state, sizeof(st), hipMemcpyDeviceToHost, s));
+    int ferr = 0;
+    if (e->fuse_err) HIP_TRY(hipMemcpyAsync(&ferr, e->fuse_err, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (ferr) return fail(PTTS_E_HIP, "fused QKV + attention launch: an attention workgroup gave up waiting for its projection (results invalid)");
     out->pos = st.pos; out->cur_len = st.cur_len; out->prompt_len = st.prompt_len;
     out->n_unfinished = st.n_unfinished; out->done_len = st.done_len; out->step_count = st.step_count;
     return PTTS_OK;
@@ -1443,10 +1475,11 @@ int ptts_get_state(ptts_engine* e, ptts_state* out, void* stream) {
 // (system-scope release: the fields are visible to the host before the stamp is).  A launch, not a copy: a device-to-host
 // hipMemcpyAsync between two graph replays cost the stream 65-105 us per poll (round 5 A/B: decode pass +0.3-0.5 % at one poll per
 // 16 steps), a one-thread kernel costs a kernel boundary.
-__global__ void snapshot_kernel(const StepState* st, volatile int* dst, int seq) {
+__global__ void snapshot_kernel(const StepState* st, const int* fuse_err, volatile int* dst, int seq) {
     if (threadIdx.x == 0) {
         dst[0] = st->pos; dst[1] = st->cur_len; dst[2] = st->prompt_len; dst[3] = st->n_unfinished; dst[4] = st->done_len;
         dst[5] = st->step_count;
+        dst[6] = fuse_err ? *fuse_err : 0;
         __atomic_store_n(const_cast<int*>(dst) + 7, seq, __ATOMIC_RELEASE);       // system scope on fine-grained host memory
     }
 }
@@ -1462,7 +1495,7 @@ int ptts_state_snapshot(ptts_engine* e, int32_t slot, void* stream) {
     hipStream_t s;
     PTTS_TRY(enter_stream(e, stream, &s));
     const int seq = ++e->snap_seq;
-    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(64), 0, s, e->state, e->snap_dev + 8 * slot, seq);
+    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(64), 0, s, e->state, (const int*)e->fuse_err, e->snap_dev + 8 * slot, seq);
     HIP_TRY(hipGetLastError());
     e->snap_want[slot] = seq;
     e->snap_stream[slot] = s;
@@ -1489,6 +1522,7 @@ int ptts_state_poll(ptts_engine* e, int32_t slot, ptts_state* out) {
         }
     }
     e->snap_want[slot] = 0;
+    if (src[6]) return fail(PTTS_E_HIP, "fused QKV + attention launch: an attention workgroup gave up waiting for its projection (results invalid)");
     out->pos = src[0]; out->cur_len = src[1]; out->prompt_len = src[2];
     out->n_unfinished = src[3]; out->done_len = src[4]; out->step_count = src[5];
     return PTTS_OK;

@@ -130,7 +130,7 @@ def test_no_mfma_is_guarded_by_exec_masking_only():
     spec = importlib.util.spec_from_file_location("check_mfma_guards", os.path.join(root, "tools", "check_mfma_guards.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    srcs = [os.path.join(root, "parler_tts_amd", "csrc", f) for f in ("gemm.hip", "conv.hip")]
+    srcs = [os.path.join(root, "parler_tts_amd", "csrc", f) for f in ("gemm.hip", "conv.hip", "fused.hip")]
     assert mod.main(srcs) == 0
 
 
@@ -148,7 +148,7 @@ def test_no_mfma_result_is_read_by_inline_asm_too_early():
     spec = importlib.util.spec_from_file_location("check_mfma_asm_hazard", os.path.join(root, "tools", "check_mfma_asm_hazard.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    srcs = [os.path.join(root, "parler_tts_amd", "csrc", f) for f in ("gemm.hip", "conv.hip", "attn.hip")]
+    srcs = [os.path.join(root, "parler_tts_amd", "csrc", f) for f in ("gemm.hip", "conv.hip", "attn.hip", "fused.hip")]
     assert mod.main(srcs) == 0
     # positive control: the round-1 pattern in ten lines must be flagged
     probe = r'''

@@ -1927,6 +1927,77 @@ def test_specialised_gemm_instances_equal_the_generic_ones_bit_for_bit(hip):
                 assert torch.equal(got, alt), (dtype, B, var, float((got - alt).abs().max()))
 
 
+def test_fused_qkv_attention_launch_equals_the_two_launches_bit_for_bit(hip):
+    """Round 5: the QKV projection and the self-attention of a decode layer run as ONE launch (csrc/fused.hip: the attention
+    workgroups are resident behind the projection workgroups of the same grid, stream the cached K rows while the projection
+    computes, and wait for their head's q / k / v through arrival tags).  Same products in the same order on both sides, only the
+    store / load instructions of the handed-over rows differ: teacher-forced logits must be BIT-IDENTICAL to the two launches of
+    rounds 1-4 (PTTS_NO_FUSED_QKV_ATTN=1) - mini_v0.1 widths, bf16 (exact-fit burst of 4 tiles) and fp32 with the folded
+    LayerNorm (8 tiles), batch 32, 19 (a ragged m-tile) and 40 (two m-tiles: tags per m-tile), prompts that cross a KV page."""
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    cfg.decoder.num_hidden_layers = 2
+    sd = synthetic_state_dict(cfg, seed=7, never_eos=True, ln_jitter=0.1, parts=("decoder",))
+    for dtype, env in (("bf16", {}), ("fp32", {"PTTS_LN_FOLD": "1"})):
+        os.environ.update(env)
+        try:
+            for B, P in ((32, 16), (19, 70), (40, 5)):
+                got, want, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=B, T=40, P=P, L=10, seed=8, steps=8)
+                assert (got - want).abs().max() < (0.1 if dtype == "bf16" else 5e-4)
+                os.environ["PTTS_NO_FUSED_QKV_ATTN"] = "1"
+                try:
+                    alt, _, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=B, T=40, P=P, L=10, seed=8, steps=8, reuse_ref=True)
+                finally:
+                    del os.environ["PTTS_NO_FUSED_QKV_ATTN"]
+                assert torch.equal(got, alt), (dtype, B, float((got - alt).abs().max()))
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
+def test_fused_qkv_attention_free_run_under_graph_replay_and_ragged_finish(hip):
+    """The fused launch over a few hundred REPLAYED steps (the arrival tags carry pos + 1 and are never reset inside a call),
+    through the public generate(): raw ids equal to the two-launch engine's, column for column, in bf16 at mini_v0.1 widths -
+    free-running over four KV pages, then with live EOS heads so that utterances finish at different steps (a finished utterance's
+    attention reads key 0 only, its workgroups still wait for their tags), then twice in a row on one engine (a new call restarts
+    pos: the tags are cleared at prefill)."""
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    cfg.decoder.num_hidden_layers = 3
+    g = torch.Generator().manual_seed(5)
+    B, T, P = 7, 12, 9
+    enc = torch.randn(B, T, cfg.text_encoder.d_model, generator=g) * 0.3
+    prompt = torch.randint(2, 32000, (B, P), generator=g)
+    outs = {}
+    for never_eos, L in ((True, 270), (False, 120)):
+        sd = synthetic_state_dict(cfg, seed=3, never_eos=never_eos, ln_jitter=0.1, parts=("decoder",))
+        for fused in (True, False):
+            if not fused:
+                os.environ["PTTS_NO_FUSED_QKV_ATTN"] = "1"
+            try:
+                _models.clear()
+                torch.cuda.empty_cache()
+                model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device="cuda:0")
+                runs = []
+                for _ in range(2):
+                    model.generate(encoder_outputs=(enc,), prompt_input_ids=prompt, do_sample=False, max_length=L, return_raw_ids=True)
+                    runs.append(model.last_raw_ids.cpu().clone())
+                assert torch.equal(runs[0], runs[1])
+                outs[(never_eos, fused)] = runs[0]
+                del model
+            finally:
+                os.environ.pop("PTTS_NO_FUSED_QKV_ATTN", None)
+        a, b = outs[(never_eos, True)], outs[(never_eos, False)]
+        assert a.shape == b.shape and torch.equal(a, b), (never_eos, a.shape, b.shape)
+    assert outs[(True, True)].shape[1] == 270
+    torch.cuda.empty_cache()
+
+
 def test_page_attention_kernel_equals_general_kernel(hip):
     """cross-attention over a single page: one-wave kernel vs the general paged kernel (same arithmetic, other order)"""
     for name in ("tiny_greedy_ragged", "tiny_cfg"):      # padded description keys / fully masked null rows

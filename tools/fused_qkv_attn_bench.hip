@@ -236,6 +236,7 @@ int main(int argc, char** argv) {
             double t[2];
             for (int fused = 0; fused < 2; ++fused) {
                 CK(hipMemset(ctl, 0, sizeof(Ctl)));
+                CK(hipDeviceSynchronize());          // the memset runs on the NULL stream: the replays below run on a non-blocking one
                 hipGraph_t g; hipGraphExec_t ge;
                 CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(64), 0, s, ctl);

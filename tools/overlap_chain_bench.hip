@@ -133,6 +133,7 @@ template <int WT, int OVL> void launch_one(const Bufs& b, hipStream_t q, int i, 
 // n dependent launches per replay; returns us per launch
 template <int WT, int OVL> double run(const Bufs& b, hipStream_t s0, hipStream_t s1, int n, int reps, int spin, bool quiet = false) {
     CK(hipMemset(b.ctl, 0, sizeof(Ctl)));
+    CK(hipDeviceSynchronize());              // the memset runs on the NULL stream: the replays run on non-blocking ones
     hipEvent_t fork, join;
     CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
     hipGraph_t g; hipGraphExec_t ge;
