@@ -263,7 +263,7 @@ class _PlumbingModel:
     ``"value": 0.0`` and ``"invalid"``, so it cannot be read as a measurement."""
 
     class _Prof:
-        algo_bytes = total_ms = launches = step_ms = steps = 0
+        algo_bytes = total_ms = launches = step_ms = steps = fused_launches = 0
 
     class _Eng:
         def profile_read(self, reset=True):
@@ -749,7 +749,9 @@ def main():
                 "mfma_fp16_tflops": round(3 * 1.61e9 * B * F / (phase["post_ms"] / args.steps / 1e3) / 1e12, 1),
                 "frac_of_fp16_dense_peak_2500": round(3 * 1.61e9 * B * F / (phase["post_ms"] / args.steps / 1e3) / 1e12 / 2500.0, 3)},
             "roofline": {
-                "kernel": "attn_decode_kernel (self-attention over the paged KV cache)",
+                "kernel": ("fused_qkv_attn_kernel (csrc/fused.hip: QKV projection + self-attention over the paged KV cache in ONE launch; bytes = "
+                           "the K/V rows + the QKV weights; PTTS_NO_FUSED_QKV_ATTN=1 runs the two launches of rounds 1-4)")
+                if getattr(prof, "fused_launches", 0) else "attn_decode_kernel (self-attention over the paged KV cache)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_derived": traffic is not None,
                 "traffic_source": traffic_src,
@@ -766,17 +768,19 @@ def main():
             dec = cfg.decoder
             esz = 2 if args.dtype == "bf16" else 4
             D_, L_, F_ = dec.hidden_size, dec.num_hidden_layers, dec.ffn_dim
-            chain_bytes = (L_ * (6 * D_ * D_ + 2 * D_ * F_ + 6 * D_) + 2 * D_ + dec.num_codebooks * dec.vocab_size * D_) * esz \
+            fused_ = bool(getattr(prof, "fused_launches", 0))          # the QKV weights then belong to the dominant kernel's bytes
+            chain_bytes = (L_ * ((3 if fused_ else 6) * D_ * D_ + 2 * D_ * F_ + 6 * D_) + 2 * D_ + dec.num_codebooks * dec.vocab_size * D_) * esz \
                 + L_ * 2 * B * T * D_ * esz
             step_ms = phase["decode_ms"] / args.steps / n_steps
             chain_ms = step_ms - L_ * (prof.total_ms / prof.launches)
             gbs = chain_bytes / 1e9 / max(chain_ms / 1e3, 1e-9)
             line["roofline_projection_chain"] = {
-                "kernel": "gemm_kernel / attn_page_kernel / select / embed launches of a decode step (all but the self-attention launches)",
+                "kernel": "gemm_kernel / attn_page_kernel / select / embed launches of a decode step (all but the "
+                          + ("fused QKV + self-attention" if fused_ else "self-attention") + " launches)",
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_step": int(chain_bytes), "ms_per_step": round(chain_ms, 4),
-                "launches_per_step": 6 * L_ + 4,
-                "derived": "decode loop ms per step (graph replay) minus layers x the sampled self-attention launch average",
+                "launches_per_step": (5 if fused_ else 6) * L_ + 4,
+                "derived": "decode loop ms per step (graph replay) minus layers x the sampled average of the dominant launch",
                 "counters": "profiles/r04_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
         if dp is not None:
             line["data_parallel"] = dp

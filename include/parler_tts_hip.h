@@ -240,13 +240,16 @@ int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* byt
 #define PTTS_DAC_KERNEL_KINDS 14
 int ptts_dac_kernel_counts(int64_t* counts_host, int32_t n, int32_t reset);
 
-/* HIP-event profile of the dominant kernel (self-attention decode): sums over the sampled launches. */
+/* HIP-event profile of the dominant kernel (self-attention decode, or - ABI v8 - the fused QKV projection + self-attention launch
+ * where a layer runs it): sums over the sampled launches. */
 typedef struct ptts_profile {
-    int64_t launches;        /* sampled self-attention launches */
+    int64_t launches;        /* sampled launches of the dominant kernel */
     double total_ms;         /* sum of their durations */
-    double algo_bytes;       /* sum of their algorithmic bytes: 2 * B_eff * S * hidden * sizeof(cache elem) */
+    double algo_bytes;       /* sum of their algorithmic bytes: 2 * B_eff * S * hidden * sizeof(cache elem), + 3 * hidden^2 *
+                                sizeof(weight) of QKV weights for a fused launch */
     int64_t steps;           /* sampled steps */
     double step_ms;          /* sum of the sampled steps' durations (eager) */
+    int64_t fused_launches;  /* how many of `launches` were the fused QKV + self-attention launch (csrc/fused.hip) */
 } ptts_profile;
 int ptts_profile_read(ptts_engine* e, ptts_profile* out_host, int32_t reset);
 

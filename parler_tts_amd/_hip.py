@@ -62,7 +62,7 @@ class PttsState(C.Structure):
 
 class PttsProfile(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("algo_bytes", C.c_double), ("steps", C.c_int64),
-                ("step_ms", C.c_double)]
+                ("step_ms", C.c_double), ("fused_launches", C.c_int64)]
 
 
 class HipLibraryMissing(RuntimeError):

@@ -447,7 +447,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             ep = &e->ev_pool[e->ev_used++];
             ep->kind = 0;
             ep->bytes = 2.0 * M * (double)(e->host_pos + 1) * D * (double)e->esz;
-            if (fuse) ep->bytes += 3.0 * D * (double)D * (double)e->esz;      // + the QKV weights the same launch streams
+            if (fuse) { ep->bytes += 3.0 * D * (double)D * (double)e->esz; ep->kind = 2; }      // + the QKV weights the same launch streams
         }
         DBG_GATE(e);
         if (fuse) {
@@ -1825,8 +1825,11 @@ int ptts_profile_read(ptts_engine* e, ptts_profile* out, int32_t reset) {
     for (size_t i = 0; i < e->ev_used; ++i) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e->ev_pool[i].a, e->ev_pool[i].b));
-        if (e->ev_pool[i].kind == 0) { e->prof.launches += 1; e->prof.total_ms += ms; e->prof.algo_bytes += e->ev_pool[i].bytes; }
-        else { e->prof.steps += 1; e->prof.step_ms += ms; }
+        const int kind = e->ev_pool[i].kind;
+        if (kind == 0 || kind == 2) {
+            e->prof.launches += 1; e->prof.total_ms += ms; e->prof.algo_bytes += e->ev_pool[i].bytes;
+            if (kind == 2) e->prof.fused_launches += 1;
+        } else { e->prof.steps += 1; e->prof.step_ms += ms; }
     }
     e->ev_used = 0;
     *out = e->prof;
