@@ -781,7 +781,7 @@ def main():
                 "algorithmic_bytes_per_step": int(chain_bytes), "ms_per_step": round(chain_ms, 4),
                 "launches_per_step": (5 if fused_ else 6) * L_ + 4,
                 "derived": "decode loop ms per step (graph replay) minus layers x the sampled average of the dominant launch",
-                "counters": "profiles/r04_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
+                "counters": "profiles/r05_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
         if dp is not None:
             line["data_parallel"] = dp
             if dp.get("equals_single_gpu") is False:

@@ -451,6 +451,8 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
         }
         DBG_GATE(e);
         if (fuse) {
+            STAMP_ARGS(e, g);             // diagnostic build: the two halves of the launch keep the two slots of the pair
+            STAMP_ARGS(e, a);
             int v = gemm_validate(g, e->dt);
             if (v != 0) return fail(PTTS_E_INVALID, "gemm shape rejected (code %d): M=%d N=%d K=%d pro=%d epi=%d", v, g.M, g.N, g.K, g.pro, g.epi);
             HIP_TRY(fused_qkv_attn_launch(g, a, M, c.heads, e->dt, e->fuse_arrive, e->fuse_err, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr));

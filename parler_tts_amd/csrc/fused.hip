@@ -98,9 +98,6 @@ template <typename P> int tiles_for(const GemmArgs& g) {
 
 bool fused_qkv_attn_supported(const GemmArgs& g, const AttnArgs& a, int dtype) {
     if (getenv("PTTS_NO_FUSED_QKV_ATTN")) return false;            // A/B and the bit-identity tests
-#ifdef PTTS_STAMPS
-    return false;                                                  // the stamp slots count launches
-#endif
     if (!g.fold || g.W2 || g.bias || g.rowmask || g.force_whole || g.rope_k || g.npos != 0 || g.epi != EPI_QKV_SELF || g.pro != PRO_FRAG) return false;
     if (g.N != 3 * g.D || g.D % 64 != 0 || g.M < 1) return false;
     if (a.pool.block_table || a.lnfix_qkv || !a.len_from_state || a.rows_per_utt != 1 || a.npos != 0) return false;

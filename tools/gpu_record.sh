@@ -8,7 +8,7 @@ python3 bench.py "$@" > "$O/bench.json" 2> "$O/bench.err"; rc=$?
 echo "bench rc=$rc"; cut -c1-300 "$O/bench.json"
 [ $rc -eq 0 ] || { tail -n 20 "$O/bench.err"; exit $rc; }
 export TMPDIR=/tmp; cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$P/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-fp32-pass "$@" > "$O/stats.log" 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$P/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-fp32-pass --no-sampling-pass "$@" > "$O/stats.log" 2>&1
 rc=$?
 echo "stats rc=$rc"
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \;

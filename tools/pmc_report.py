@@ -33,7 +33,9 @@ if mode == "decoder":
             ("gemm_kernel<PBF16, 16, 1, false, 1, 1, false, 1, 0, 0, 8, true>", 256): "fc2 + residual (quarter rows)         8.39 MB",
             ("gemm_kernel<PBF16, 8, 1, false, 1, 2, true, 0, 0, 0, 4, false>", 612): "final LN + 9 LM heads (folded)      20.05 MB",
             ("gemm_kernel<PBF16, 8, 3, false, 1, 2, true, 0, 0, 0, 4, false>", 204): "final LN + 9 LM heads (folded, NB = 3) 20.05 MB",
-            ("attn_decode_kernel<PBF16, PBF16, true, 0>", 512): "self-attention, S ~ 1266            165.9 MB"}
+            ("attn_decode_kernel<PBF16, PBF16, true, 0>", 512): "self-attention, S ~ 1266            165.9 MB",
+            # round 5: QKV projection + self-attention in ONE launch (csrc/fused.hip): 192 projection + 512 attention workgroups
+            ("fused_qkv_attn_kernel<PBF16, 4>", 704): "LN1 + QKV + self-attention, S ~ 1266 172.2 MB"}
     print("kernel (workgroups x threads)                                          launch = algorithmic weight/KV bytes      | fabric rd MB  wr MB | L2 hit % | "
           "L1->L2 read latency (cycles) | wave cycles: issuing % / parked on s_waitcnt+barrier % / issue-stalled % | MFMA busy cycles (summed over the SIMDs) per 100 SQ busy cycles")
     for k, r in sorted(t1.items(), key=lambda x: -x[1]["mean_ns"] * x[1]["launches"]):

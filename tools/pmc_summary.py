@@ -19,7 +19,7 @@ for f in files:
         if int(r["Dispatch_Id"]) < min_id:
             continue
         name = r["Kernel_Name"]
-        short = name.split("(anonymous namespace)::")[-1][:70]
+        short = name.split("(anonymous namespace)::", 1)[-1][:70]     # the FIRST marker: an argument type may carry it too (FusedArgs)
         key = (short, int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1), int(r["Workgroup_Size"]))
         g = agg.setdefault(key, dict(ids=set(), counters=collections.defaultdict(float), ns=0.0, vgpr=r.get("VGPR_Count"),
                                      agpr=r.get("Accum_VGPR_Count"), sgpr=r.get("SGPR_Count"), lds=r.get("LDS_Block_Size")))
