@@ -59,7 +59,7 @@ template <> __device__ inline void fused_load_q_sc1<8>(const float* p, float (&q
 
 #define PTTS_ATTN_FUSED 1
 #define PTTS_ATTN_SIGNATURE __device__ __forceinline__ void attn_body(AttnArgs a, const int attn_h, const int attn_b, const int* fused_arrive, \
-                                                                      const int fused_mtiles, int* fused_err)
+                                                                      const int fused_mtiles, int* fused_err, const int fused_pre, const int fused_delay)
 #define PTTS_ATTN_H attn_h
 #define PTTS_ATTN_B attn_b
 #include "attn_device.inc"
@@ -70,16 +70,25 @@ struct FusedArgs {
     int* arrive;
     int* err;
     int n_gemm, nblk, mtiles, heads;
+    int pre, delay;                    // early K bursts per attention workgroup (0 .. 2) and s_sleep(16) units in front of them
 };
 
+// diagnostic build only: the in-kernel stamps cost 16 registers (84 instead of 68: two workgroups per CU instead of three, i.e. a third
+// of the attention workgroups would start only when the projection workgroups have left - not the product's timeline); hold the
+// stamped kernel to the product's occupancy class
+#ifdef PTTS_STAMPS
+#define PTTS_FUSED_OCC __attribute__((amdgpu_waves_per_eu(6)))
+#else
+#define PTTS_FUSED_OCC
+#endif
 template <typename P, int TILES>
-__global__ __launch_bounds__(512) void fused_qkv_attn_kernel(FusedArgs f) {
+__global__ __launch_bounds__(512) PTTS_FUSED_OCC void fused_qkv_attn_kernel(FusedArgs f) {
     const int i = blockIdx.x;
     if (i < f.n_gemm) {
         gemm_body<P, 8, 1, false, 1, 2, true, EPI_QKV_SELF, ACT_NONE, 0, TILES, false>(f.g, i % f.nblk, i / f.nblk, f.arrive, f.mtiles, f.heads);
     } else {
         const int j = i - f.n_gemm;
-        attn_body<P, P, true, 0>(f.a, j % f.heads, j / f.heads, f.arrive, f.mtiles, f.err);
+        attn_body<P, P, true, 0>(f.a, j % f.heads, j / f.heads, f.arrive, f.mtiles, f.err, f.pre, f.delay);
     }
 }
 
@@ -116,6 +125,9 @@ hipError_t fused_qkv_attn_launch(const GemmArgs& g, const AttnArgs& a, int M, in
     f.g = g; f.a = a; f.arrive = arrive; f.err = err;
     f.nblk = g.N / 16; f.mtiles = (M + 31) / 32; f.heads = heads;
     f.n_gemm = f.nblk * f.mtiles;
+    static const int pre_env = getenv("PTTS_FUSED_PRE") ? atoi(getenv("PTTS_FUSED_PRE")) : 2;          // experiment switches
+    static const int delay_env = getenv("PTTS_FUSED_DELAY") ? atoi(getenv("PTTS_FUSED_DELAY")) : 0;
+    f.pre = pre_env; f.delay = delay_env;
     // dynamic LDS: the larger of the two halves (K-split hand-over + statistics of the projection; scores + partial outputs of the attention)
     const size_t lds_g = (size_t)8 * 1 * 2 * 64 * 16 + (size_t)8 * 2 * 2 * 16 * 4;
     const size_t lds_a = ((size_t)a.s_cap + 8 * 64 + 8 + a.pool.max_blocks + 64) * sizeof(float);
