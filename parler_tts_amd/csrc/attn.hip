@@ -37,12 +37,16 @@ namespace {
 // kernel above spends ~6.7 us on a 40-key context (8 waves, 8 barriers); this one has a single
 // dependent global access (page id -> tiles).
 // ------------------------------------------------------------------------------------------------
-template <typename P, typename OP>
+// NTU > 0 (round 5): the host knows the context covers at most NTU tiles (a 40-key description = 5 of the page's 8 bf16 tiles): only
+// those are requested and scored.  A tile past the context contributes exp(-inf) = 0 to the sum, p = 0 to P.V and -inf to the max,
+// so dropping it changes no bit of the result - but it was 2 of every 16 loads per lane, a third of the score / P.V arithmetic
+// and 24 of the kernel's 142 registers.
+template <typename P, typename OP, int NTU = 0>
 __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
     typedef typename P::elem_t elem_t;
     typedef KVLoad<P> L;
     typedef typename L::raw_t raw_t;
-    constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT, NT = 64 / TPW;   // NT tiles cover one page
+    constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT, NT = NTU > 0 ? NTU : 64 / TPW;   // NT tiles: the page, or the part of it in use
     const int lane = threadIdx.x & 63;
 #ifdef PTTS_STAMPS
     // 0 realtime at entry, 1 cycles at entry, 6 cycles at the end, 7 realtime at exit (wave 0 of the workgroup)
@@ -406,13 +410,23 @@ hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, 
                               hipEvent_t ev_stop) {
     if (!a.no_page_kernel && !a.len_from_state && a.len <= PTTS_PAGE_TOKENS) {
         dim3 pgrid((H + 3) / 4, B), pblock(256);
+        // tiles of the page the context reaches (8 keys per bf16 tile, 4 per fp32 tile); PTTS_ATTN_PAGE_FULL=1: always the whole page (A/B)
+        static const bool full_page = getenv("PTTS_ATTN_PAGE_FULL") != nullptr;
+        const int tiles = full_page ? 64 : (a.len + (cache_dtype == PTTS_BF16 ? 7 : 3)) / (cache_dtype == PTTS_BF16 ? 8 : 4);
+#define PTTS_PAGE_LAUNCH(P_, O_, N1, N2)                                                                                   \
+        do {                                                                                                                 \
+            if (tiles <= N1) hipLaunchKernelGGL((attn_page_kernel<P_, O_, N1>), pgrid, pblock, 0, stream, a, H);             \
+            else if (tiles <= N2) hipLaunchKernelGGL((attn_page_kernel<P_, O_, N2>), pgrid, pblock, 0, stream, a, H);        \
+            else hipLaunchKernelGGL((attn_page_kernel<P_, O_, 0>), pgrid, pblock, 0, stream, a, H);                          \
+        } while (0)
         if (cache_dtype == PTTS_BF16) {
-            if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_page_kernel<PBF16, PBF16>), pgrid, pblock, 0, stream, a, H);
-            else hipLaunchKernelGGL((attn_page_kernel<PBF16, PF32>), pgrid, pblock, 0, stream, a, H);
+            if (out_dtype == PTTS_BF16) PTTS_PAGE_LAUNCH(PBF16, PBF16, 3, 5);
+            else PTTS_PAGE_LAUNCH(PBF16, PF32, 3, 5);
         } else {
-            if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_page_kernel<PF32, PBF16>), pgrid, pblock, 0, stream, a, H);
-            else hipLaunchKernelGGL((attn_page_kernel<PF32, PF32>), pgrid, pblock, 0, stream, a, H);
+            if (out_dtype == PTTS_BF16) PTTS_PAGE_LAUNCH(PF32, PBF16, 5, 10);
+            else PTTS_PAGE_LAUNCH(PF32, PF32, 5, 10);
         }
+#undef PTTS_PAGE_LAUNCH
         return hipGetLastError();
     }
     size_t lds = ((size_t)a.s_cap + NWAVES * 64 + NWAVES + a.pool.max_blocks + 64) * sizeof(float);   // + 64: look-ahead q
