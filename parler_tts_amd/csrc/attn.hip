@@ -37,184 +37,10 @@ namespace {
 // kernel above spends ~6.7 us on a 40-key context (8 waves, 8 barriers); this one has a single
 // dependent global access (page id -> tiles).
 // ------------------------------------------------------------------------------------------------
-// NTU > 0 (round 5): the host knows the context covers at most NTU tiles (a 40-key description = 5 of the page's 8 bf16 tiles): only
-// those are requested and scored.  A tile past the context contributes exp(-inf) = 0 to the sum, p = 0 to P.V and -inf to the max,
-// so dropping it changes no bit of the result - but it was 2 of every 16 loads per lane, a third of the score / P.V arithmetic
-// and 24 of the kernel's 142 registers.
-template <typename P, typename OP, int NTU = 0>
-__global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H) {
-    typedef typename P::elem_t elem_t;
-    typedef KVLoad<P> L;
-    typedef typename L::raw_t raw_t;
-    constexpr int LPT = L::LPT, EPL = L::EPL, TPW = 64 / LPT, NT = NTU > 0 ? NTU : 64 / TPW;   // NT tiles: the page, or the part of it in use
-    const int lane = threadIdx.x & 63;
-#ifdef PTTS_STAMPS
-    // 0 realtime at entry, 1 cycles at entry, 6 cycles at the end, 7 realtime at exit (wave 0 of the workgroup)
-    unsigned long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const StampRef stref = a.stamps;
-    stv[0] = stamp_realtime();
-    stv[1] = stamp_cycles();
-#endif
-#ifndef PTTS_EXP_NO_PAGE_PIN
-    // every kernel-argument field in ONE scalar-memory round trip (see attn_decode_kernel)
-    asm volatile("" :: "s"(a.q), "s"(a.pool.base), "s"(a.pool.block_table), "s"(a.bias), "s"(a.bias_flag), "s"(a.ofrag), "s"(a.lnfix_stat), "s"(a.lnfix_c1),
-                 "s"(a.lnfix_c2), "s"(a.ldq), "s"(a.layer), "s"(a.len), "s"(a.pool.max_blocks), "s"(a.pool.H), "s"(a.pool.n_pages),
-                 "s"(a.rows_per_utt), "s"(a.lnfix_blocks), "s"(a.ld_bias), "s"(a.D), "s"(H));
-#endif
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
-    if (h >= H) return;
-    const int bu = b / a.rows_per_utt;          // query row b reads utterance bu's page and mask row
-    const int S = a.len;
-    const int tt = lane / LPT, c = lane % LPT;
-    const elem_t* pool = reinterpret_cast<const elem_t*>(a.pool.base);
-    // Load order (vector-memory results return in issue order): the small L2-resident operands first - look-ahead statistics
-    // and fold constants, the query, the mask - then the 2 x NT key / value tiles; nothing is waited for until everything has
-    // been requested.  (Round 3 found the statistics loop BEHIND the tiles with an s_waitcnt vmcnt(0) per iteration, and the
-    // fold constants behind that: three serial memory round trips, 3500 of the launch's ~8500 cycles in front of the arithmetic.)
-    const bool lnfix = a.lnfix_stat != nullptr;
-    // every request below is UNCONDITIONAL straight-line code (indices clamped, pointers replaced by a readable dummy when the
-    // look-ahead is off): a load inside an `if` makes hipcc wait for it at the join, in front of everything stated later
-    const float* sp = lnfix ? a.lnfix_stat + ((size_t)(b >> 5) * a.lnfix_blocks * 32 + (b & 31)) * 2 : a.q;
-    const int nblk = lnfix ? a.lnfix_blocks : 1;
-    // one 16-column block per lane and request: two requests cover rows of up to 2048 features (wider rows: the loop further down)
-    const float2 p0 = *reinterpret_cast<const float2*>(sp + (size_t)(lane < nblk ? lane : nblk - 1) * (lnfix ? 64 : 0));
-    const float2 p1 = *reinterpret_cast<const float2*>(sp + (size_t)(lane + 64 < nblk ? lane + 64 : nblk - 1) * (lnfix ? 64 : 0));
-    const float* c1p = lnfix ? a.lnfix_c1 + h * PTTS_HEAD_DIM + c * EPL : a.q;
-    const float* c2p = lnfix ? a.lnfix_c2 + h * PTTS_HEAD_DIM + c * EPL : a.q;
-    f32x4 c1r[EPL / 4], c2r[EPL / 4];
-#pragma unroll
-    for (int j = 0; j < EPL / 4; ++j) {
-        c1r[j] = reinterpret_cast<const f32x4*>(c1p)[j];
-        c2r[j] = reinterpret_cast<const f32x4*>(c2p)[j];
-    }
-    float q[EPL];
-    {
-        const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)b * a.ldq + h * PTTS_HEAD_DIM + c * EPL);
-#pragma unroll
-        for (int j = 0; j < EPL / 4; ++j) {
-            const f32x4 v = qp[j];
-            q[4 * j] = v[0]; q[4 * j + 1] = v[1]; q[4 * j + 2] = v[2]; q[4 * j + 3] = v[3];
-        }
-    }
-    // (a table entry is uniform per wave: read through the scalar cache, it does not join the vector-memory queue - a
-    // conditional vector load here made hipcc drain vmcnt in front of the tiles)
-    // scalar_load invariant: the block table is host-written, bias_flag by build_bias_kernel at prefill; never by this kernel
-    const int page = a.pool.block_table ? scalar_load_int(a.pool.block_table + bu * a.pool.max_blocks) : bu * a.pool.max_blocks;
-    const elem_t* kp = pool + (size_t)a.layer * 2 * a.pool.kv_elems() + (size_t)h * a.pool.head_elems() +
-                       (size_t)page * a.pool.page_elems() + c * EPL;
-    const size_t v_off = a.pool.kv_elems();
-    // every tile of the page is requested unconditionally (token index clamped to S-1): straight-line code, so all
-    // 2*NT loads are in flight together; tiles past S are masked out of the arithmetic instead
-    raw_t kb[NT], vb[NT];
-    float bs[NT];
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        int tok = u * TPW + tt;
-        tok = tok < S ? tok : S - 1;
-        kb[u] = *reinterpret_cast<const raw_t*>(kp + (size_t)tok * PTTS_HEAD_DIM);
-    }
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        int tok = u * TPW + tt;
-        tok = tok < S ? tok : S - 1;
-        vb[u] = *reinterpret_cast<const raw_t*>(kp + v_off + (size_t)tok * PTTS_HEAD_DIM);
-    }
-    // an all-ones description mask (every equal-length batch) leaves the bias all zero: build_bias_kernel says so in a device
-    // word, read through the scalar cache; the uniform branch below then drops the NT mask loads of every lane
-    const bool has_bias = a.bias != nullptr && (a.bias_flag == nullptr || scalar_load_int(a.bias_flag) != 0);
-    const float* brow = a.bias + (size_t)bu * a.ld_bias;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) bs[u] = 0.f;
-    if (has_bias) {
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            int tok = u * TPW + tt;
-            tok = tok < S ? tok : S - 1;
-            bs[u] = brow[tok];
-        }
-    }
-#ifdef PTTS_STAMPS
-    stv[2] = stamp_cycles();                    // every load issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stv[3] = stamp_cycles();                    // ... and landed (diagnostic build only)
-#endif
-    // hipcc otherwise sinks the V loads below the score arithmetic; an empty asm use pins every load above this point
-#pragma unroll
-    for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(kb[u]));
-#pragma unroll
-    for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(vb[u]));
-    if (lnfix) {
-        float st_s = (lane < nblk ? p0.x : 0.f) + (lane + 64 < nblk ? p1.x : 0.f);
-        float st_q = (lane < nblk ? p0.y : 0.f) + (lane + 64 < nblk ? p1.y : 0.f);
-        for (int nbk = lane + 128; nbk < nblk; nbk += 64) {        // rows wider than 2048 features
-            st_s += sp[(size_t)nbk * 64];
-            st_q += sp[(size_t)nbk * 64 + 1];
-        }
-        float fc1[EPL], fc2[EPL];
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) { fc1[j] = c1r[j >> 2][j & 3]; fc2[j] = c2r[j >> 2][j & 3]; }
-        const float K = (float)(a.lnfix_blocks * 16);
-        const float mean = a.lnfix_rms ? 0.f : wave_sum(st_s) / K;
-        const float var = a.lnfix_rms ? wave_sum(st_q) / K : fmaxf(wave_sum(st_q) / K - mean * mean, 0.f);
-        const float rstd = 1.0f / sqrtf(var + a.lnfix_eps);
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) q[j] = a.lnfix_scale * (rstd * (q[j] - mean * fc1[j]) + fc2[j]);
-    }
-    // scores: every lane of a token row ends up with the row's full dot product
-    float sc[NT];
-    float m = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        float kf[EPL];
-        L::unpack(kb[u], kf);
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) d = fmaf(q[j], kf[j], d);
-        d = (LPT == 8) ? sum_oct(d) : sum_row16(d);
-        sc[u] = (u * TPW + tt < S) ? d + bs[u] : -INFINITY;
-        m = fmaxf(m, sc[u]);
-    }
-    // across the token-lanes (lanes with equal c): xor 8 (bf16 only), 16, 32
-    if (LPT == 8) m = fmaxf(m, dpp_f<0x128>(m));
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        sc[u] = (u * TPW + tt < S) ? expf(sc[u] - m) : 0.f;
-        sum += sc[u];
-    }
-    if (LPT == 8) sum += dpp_f<0x128>(sum);
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    float acc[EPL];
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        const float p = sc[u] / sum;
-        float vf[EPL];
-        L::unpack(vb[u], vf);
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        if (LPT == 8) acc[j] += dpp_f<0x128>(acc[j]);
-        acc[j] += __shfl_xor(acc[j], 16);
-        acc[j] += __shfl_xor(acc[j], 32);
-    }
-    if (tt == 0) {
-        typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(b >> 5) * 32 * a.D;
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) of[frag_off<OP>(b & 31, h * PTTS_HEAD_DIM + c * EPL + j)] = to_elem<OP>(acc[j]);
-    }
-#ifdef PTTS_STAMPS
-    stv[6] = stamp_cycles();
-    stv[7] = stamp_realtime();
-    stamp_store(stref, stv);
-#endif
-}
+#define PTTS_PAGE_SIGNATURE __global__ __launch_bounds__(256) void attn_page_kernel(AttnArgs a, int H)
+#define PTTS_PAGE_H (blockIdx.x * 4 + (threadIdx.x >> 6))
+#define PTTS_PAGE_B blockIdx.y
+#include "attn_page_device.inc"
 
 // ------------------------------------------------------------------------------------------------
 // Causal self-attention of a batched prefill chunk (reference M:264-382 with tgt_len = npos under the 4-D causal mask

@@ -1946,12 +1946,17 @@ def test_fused_qkv_attention_launch_equals_the_two_launches_bit_for_bit(hip):
             for B, P in ((32, 16), (19, 70), (40, 5)):
                 got, want, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=B, T=40, P=P, L=10, seed=8, steps=8)
                 assert (got - want).abs().max() < (0.1 if dtype == "bf16" else 5e-4)
-                os.environ["PTTS_NO_FUSED_QKV_ATTN"] = "1"
-                try:
-                    alt, _, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=B, T=40, P=P, L=10, seed=8, steps=8, reuse_ref=True)
-                finally:
-                    del os.environ["PTTS_NO_FUSED_QKV_ATTN"]
-                assert torch.equal(got, alt), (dtype, B, float((got - alt).abs().max()))
+                # ... and with the out-projection (+ look-ahead query) + cross-attention pair fused the same way (PTTS_FUSED_OUT_CROSS=1:
+                # an experiment that is OFF by default - parity-green, measured slower; csrc/fused.hip)
+                for off in (("PTTS_NO_FUSED_QKV_ATTN",), ("PTTS_FUSED_OUT_CROSS",), ("PTTS_NO_FUSED_QKV_ATTN", "PTTS_FUSED_OUT_CROSS")):
+                    for k in off:
+                        os.environ[k] = "1"
+                    try:
+                        alt, _, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=B, T=40, P=P, L=10, seed=8, steps=8, reuse_ref=True)
+                    finally:
+                        for k in off:
+                            del os.environ[k]
+                    assert torch.equal(got, alt), (dtype, B, off, float((got - alt).abs().max()))
         finally:
             for k in env:
                 del os.environ[k]
