@@ -22,11 +22,13 @@ def test_every_collective_of_the_dp_path_runs_on_rccl_world_size_1():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [["12", "7"], ["8", "7", "generate"], ["10", "7", "bf16"]], ids=["teacher_forced", "generate_api", "bf16"])
+@pytest.mark.parametrize("args", [["12", "7"], ["8", "7", "generate"], ["10", "7", "bf16"], ["8", "7", "fused"]],
+                         ids=["teacher_forced", "generate_api", "bf16", "fused_launch"])
 def test_randomised_parity_sweep(args):
     """tools/fuzz_parity.py in a child process: random tiny architectures and call shapes the fixtures do not cover (codebooks 1 .. 32,
     batch 1 .. 40, prompts across the 64-token KV page, ragged masks; with `generate`: the public call, free-running, live EOS heads,
-    guidance) - fp32 engine vs the oracle.  A fixed seed: the same cases on every run."""
+    guidance) - fp32 engine vs the oracle; `fused` (round 5): decoders wide enough for the fused QKV + self-attention launch, batch up
+    to three m-tiles, against the two launches of rounds 1-4, bit for bit.  A fixed seed: the same cases on every run."""
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: the -m gpu tests must run on an MI355X box")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")] + args, capture_output=True, text=True, timeout=900, cwd=ROOT)

@@ -3,7 +3,12 @@
 fixtures do not cover - codebooks 1 .. 32, hidden 64 .. 256, 1-3 layers, batch 1 .. 40, descriptions 1 .. 90 tokens, prompts
 0 .. 90 tokens (page crossings at 64), max_length from K + 2 up, ragged masks.  Teacher-forced along the oracle's greedy path:
 logits within 2e-4 and the argmax equal wherever the oracle's top-2 margin exceeds 1e-3.
-    python3 tools/fuzz_parity.py [n_cases] [seed] [generate | bf16]
+    python3 tools/fuzz_parity.py [n_cases] [seed] [generate | bf16 | fused]
+With the third argument `fused` (round 5): decoders WIDE enough for the fused QKV + self-attention launch (hidden 768 / 1024 / 1536,
+1-2 layers, 1-17 codebooks, batch 1 .. 70 = up to three m-tiles, prompts across KV pages, ragged masks, guidance, live EOS heads):
+the public `generate()` free-running under graph replay, with the fused launch and with the two launches of rounds 1-4
+(PTTS_NO_FUSED_QKV_ATTN=1) - raw ids and the last step's logits must be BIT-IDENTICAL (no oracle involved: the two forms are the
+same arithmetic, only the hand-off differs).
 With the third argument `generate`: the public `generate()` call, free-running greedy, LIVE EOS heads, optionally classifier-free
 guidance and ragged masks, against `cpu_ref.generate_ids`: the raw ids must agree up to (per utterance) the first step the oracle
 itself decides by less than 1e-3; with no such step the codes and the number of columns must be equal.
@@ -129,6 +134,78 @@ def generate_case(case):
     return ok
 
 
+def fused_case(case):
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+
+    D = int(rng.choice([768, 1024, 1024, 1536]))
+    K = int(rng.choice([1, 4, 9, 9, 17]))
+    layers = int(rng.integers(1, 3))
+    B = int(rng.choice([1, 2, 7, 16, 19, 32, 33, 40, 70]))
+    T = int(rng.choice([1, 5, 12, 40, 63]))
+    P = int(rng.choice([0, 1, 16, 63, 65, 130]))
+    L = int(K + 4 + rng.integers(4, 60))
+    gs = float(rng.choice([0.0, 0.0, 3.0])) if B <= 35 else 0.0
+    dtype = "bf16" if rng.integers(0, 4) else "fp32"
+    ragged = bool(rng.integers(0, 2)) and T >= 4 and P >= 2
+    never_eos = bool(rng.integers(0, 2))
+    tag = f"case {case} [{dtype}]: D {D} K {K} layers {layers} B {B} T {T} P {P} L {L} guidance {gs} ragged {ragged} never_eos {never_eos}"
+    cfg = mini_v01_config()
+    dec = cfg.decoder
+    dec.hidden_size, dec.num_attention_heads, dec.ffn_dim, dec.num_hidden_layers, dec.num_codebooks = D, D // 64, 2 * D, layers, K
+    cfg.audio_encoder.num_codebooks = K
+    sd = synthetic_state_dict(cfg, seed=int(rng.integers(1, 1000)), never_eos=never_eos, ln_jitter=0.1, parts=("decoder",))
+    g = torch.Generator().manual_seed(int(rng.integers(1, 1000)))
+    enc = torch.randn(B, T, cfg.text_encoder.d_model, generator=g) * 0.3
+    prompt = torch.randint(2, 32000, (B, P), generator=g) if P else None
+    amask = torch.ones(B, T, dtype=torch.long)
+    pmask = None
+    if ragged:
+        pmask = torch.ones(B, P, dtype=torch.long)
+        for b in range(1, B):
+            amask[b, T - (7 * b) % (T // 2):] = 0
+            pmask[b, : (5 * b) % (P // 2 + 1)] = 0
+    kw = dict(encoder_outputs=(enc,), attention_mask=amask, do_sample=False, max_length=L, return_raw_ids=True)
+    if prompt is not None:
+        kw["prompt_input_ids"] = prompt
+    if pmask is not None:
+        kw["prompt_attention_mask"] = pmask
+    if gs > 1:
+        kw["guidance_scale"] = gs
+    outs = []
+    env = {"PTTS_LN_FOLD": "1"} if dtype == "fp32" else {}
+    for fused in (True, False):
+        os.environ.update(env)
+        if not fused:
+            os.environ["PTTS_NO_FUSED_QKV_ATTN"] = "1"
+        try:
+            model = ParlerTTSForConditionalGeneration(cfg, sd, dtype=dtype, device="cuda:0")
+            model.generate(**kw)
+            eng = model.engine()
+            rows = (2 * B if gs > 1 else B) * K
+            prof = eng.profile_read(reset=True)
+            outs.append((model.last_raw_ids.cpu().clone(), eng.last_logits(rows).cpu().clone()))
+            del model
+            torch.cuda.empty_cache()
+        finally:
+            os.environ.pop("PTTS_NO_FUSED_QKV_ATTN", None)
+            for k in env:
+                os.environ.pop(k, None)
+    ok = outs[0][0].shape == outs[1][0].shape and bool(torch.equal(outs[0][0], outs[1][0])) and bool(torch.equal(outs[0][1], outs[1][1]))
+    print(f"{'ok  ' if ok else 'FAIL'} {tag}: columns {tuple(outs[0][0].shape)} vs {tuple(outs[1][0].shape)}, ids and last logits bit-identical {ok}", flush=True)
+    return ok
+
+
+for case in range(n_cases if MODE == "fused" else 0):
+    try:
+        fails += 0 if fused_case(case) else 1
+    except Exception as e:
+        fails += 1
+        print(f"EXC  case {case}: {type(e).__name__}: {e}", flush=True)
+        traceback.print_exc()
+if MODE == "fused":
+    print(f"{n_cases - fails} of {n_cases} cases passed")
+    sys.exit(1 if fails else 0)
 for case in range(n_cases if MODE == "generate" else 0):
     try:
         fails += 0 if generate_case(case) else 1
