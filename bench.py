@@ -623,6 +623,10 @@ def main():
         backend = "gloo" if plumbing else os.environ.get("PTTS_DIST_BACKEND", "nccl")
         if os.environ.get("PTTS_SHARE_GPU"):
             local_rank = 0
+            # several processes on ONE card (rehearsal only): with every process keeping its queue full through generate()'s own
+            # stream the shared card time-slices badly (2 ranks: 14.9-18.0 s per pass instead of 6.2 s, profiles/r05_dp2_*); the
+            # host-synchronous NULL-stream path of rounds 1-4 drains the queue every few steps and shares well
+            os.environ.setdefault("PTTS_NO_SIDE_STREAM", "1")
         if backend == "nccl":
             if local_rank >= torch.cuda.device_count():
                 raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")

@@ -299,6 +299,28 @@ class HipEngine:
 _hiprt = None
 
 
+def _own_stream(device: torch.device) -> "torch.cuda.ExternalStream":
+    """ONE non-blocking HIP stream, created directly and handed to torch as an ExternalStream (`torch.cuda.Stream()` draws from
+    torch's pool, which creates 32 streams per priority level on first use; the engine needs one queue, not 64).
+    Note for SHARED cards (several processes on one GPU - not the deployment, one process per GPU is): a process that keeps its
+    queue full through this stream shares badly - the 2-rank shared-GPU rehearsal of the benchmark takes 14.9-18.0 s per pass
+    against 6.2 s on the host-synchronous NULL-stream path, which drains the queue every few steps.  `PTTS_NO_SIDE_STREAM=1`
+    selects that path (bench.py sets it under PTTS_SHARE_GPU)."""
+    global _hiprt
+    if _hiprt is None:
+        _hiprt = C.CDLL("libamdhip64.so")
+        _hiprt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hiprt.hipMemcpy.restype = C.c_int
+    _hiprt.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    _hiprt.hipStreamCreateWithFlags.restype = C.c_int
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = _hiprt.hipStreamCreateWithFlags(C.byref(h), 1)        # hipStreamNonBlocking
+    if rc != 0 or not h.value:
+        raise RuntimeError(f"hipStreamCreateWithFlags failed: {rc}")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 def _hipMemcpyDtoD(dst: int, src: int, nbytes: int) -> int:
     global _hiprt
     if _hiprt is None:
@@ -556,7 +578,7 @@ class ParlerTTSForConditionalGeneration:
         # every stream handle, lazy allocation and launch below follows the CURRENT device: make it the model's
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream(self.device)
-            if cur.cuda_stream != 0 or os.environ.get("PTTS_LEGACY_POLL"):
+            if cur.cuda_stream != 0 or os.environ.get("PTTS_LEGACY_POLL") or os.environ.get("PTTS_NO_SIDE_STREAM"):
                 return self._generate(inputs, generation_config, logits_processor, stopping_criteria, synced_gpus, streamer,
                                       **kwargs)
             # The legacy NULL stream cannot be captured into a hipGraph and every engine call on it is host-synchronous
@@ -564,7 +586,7 @@ class ParlerTTSForConditionalGeneration:
             # for what the caller has queued on the NULL stream, and the NULL stream waits for it at the end, so the caller
             # sees the ordering of the stream it called from.
             if getattr(self, "_side_stream", None) is None or self._side_stream.device != self.device:
-                self._side_stream = torch.cuda.Stream(device=self.device)
+                self._side_stream = _own_stream(self.device)
             side = self._side_stream
             side.wait_stream(cur)
             try:
