@@ -164,6 +164,7 @@ struct ptts_engine {
     // fused QKV + self-attention launch (fused.hip): arrival tags [layers][m-tiles][heads][32] + an error word (bounded spins)
     int* fuse_arrive = nullptr;
     int* fuse_err = nullptr;
+    int* fuse_blackhole = nullptr;      // PTTS_FUSED_TEST_BREAK=1: the producers' tags go here (test of the time-out path)
     size_t fuse_arrive_ints = 0;
     // fused out-projection + cross-attention launch: its own tags, and an output buffer of its own for the cross-attention half (the
     // out-projection workgroups of the same launch are still reading the self-attention's output from attn_frag)
@@ -463,7 +464,7 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             STAMP_ARGS(e, a);
             int v = gemm_validate(g, e->dt);
             if (v != 0) return fail(PTTS_E_INVALID, "gemm shape rejected (code %d): M=%d N=%d K=%d pro=%d epi=%d", v, g.M, g.N, g.K, g.pro, g.epi);
-            HIP_TRY(fused_qkv_attn_launch(g, a, M, c.heads, e->dt, e->fuse_arrive, e->fuse_err, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr));
+            HIP_TRY(fused_qkv_attn_launch(g, a, M, c.heads, e->dt, e->fuse_arrive, e->fuse_err, s, ep ? ep->a : nullptr, ep ? ep->b : nullptr, e->fuse_blackhole));
         } else if (npos > 0) {
             a.npos = npos; a.pos0 = pos0;
             HIP_TRY(attn_causal_launch(a, B_utt, c.heads, e->dt, e->dt, s));
@@ -1033,6 +1034,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->fuse_qkv_attn = getenv("PTTS_NO_FUSED_QKV_ATTN") == nullptr;
     e->fuse_arrive_ints = fused_arrive_ints(cfg->layers, e->mtiles, cfg->heads) + 32;
     A(e->fuse_arrive, sizeof(int) * e->fuse_arrive_ints);          // the last 32 ints: the error word (own line)
+    if (getenv("PTTS_FUSED_TEST_BREAK")) A(e->fuse_blackhole, sizeof(int) * e->fuse_arrive_ints);
     e->fuse_out_cross = getenv("PTTS_FUSED_OUT_CROSS") != nullptr;        // experiment, OFF by default: measured slower (fused.hip)
     e->fuse2_arrive_ints = fused2_arrive_ints(cfg->layers, e->mtiles, D / 16);
     A(e->fuse2_arrive, sizeof(int) * e->fuse2_arrive_ints);

@@ -10,8 +10,10 @@ inline size_t fused_arrive_ints(int layers, int mtiles, int heads) { return (siz
 // instance with an exact-fit tile burst (K / KSTEP = 8 x 4 or 8 x 8), identity page table, no look-ahead QKV, no rotary variant
 bool fused_qkv_attn_supported(const GemmArgs& g, const AttnArgs& a, int dtype);
 // ev_start / ev_stop as in attn_decode_launch (bound to the dispatch)
+// arrive_prod: test hook (PTTS_FUSED_TEST_BREAK=1 at engine creation) - the projection half stores its tags THERE instead of in `arrive`, so the
+// attention half never sees them: its bounded, sticky time-out and the error path of the call can be tested
 hipError_t fused_qkv_attn_launch(const GemmArgs& g, const AttnArgs& a, int M, int heads, int dtype, int* arrive, int* err,
-                                 hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                 hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int* arrive_prod = nullptr);
 
 // Out-projection (+ look-ahead query) and cross-attention of a decode layer as ONE launch (fused.hip).  Arrival tags:
 // [layers][m-tiles][2 halves][2 roles][blocks = N / 16] ints, zeroed at every prefill.

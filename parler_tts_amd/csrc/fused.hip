@@ -95,6 +95,7 @@ struct FusedArgs {
     GemmArgs g;
     AttnArgs a;
     int* arrive;
+    int* arrive_prod;                  // where the projection half stores its tags: = arrive (a test hook points it elsewhere: the attention half then times out)
     int* err;
     int n_gemm, nblk, mtiles, heads;
     int pre, delay;                    // early K bursts per attention workgroup (0 .. 2) and s_sleep(16) units in front of them
@@ -112,7 +113,7 @@ template <typename P, int TILES>
 __global__ __launch_bounds__(512) PTTS_FUSED_OCC void fused_qkv_attn_kernel(FusedArgs f) {
     const int i = blockIdx.x;
     if (i < f.n_gemm) {
-        gemm_body<P, 8, 1, false, 1, 2, true, EPI_QKV_SELF, ACT_NONE, 0, TILES, false>(f.g, i % f.nblk, i / f.nblk, f.arrive, f.mtiles, f.heads);
+        gemm_body<P, 8, 1, false, 1, 2, true, EPI_QKV_SELF, ACT_NONE, 0, TILES, false>(f.g, i % f.nblk, i / f.nblk, f.arrive_prod, f.mtiles, f.heads);
     } else {
         const int j = i - f.n_gemm;
         attn_body<P, P, true, 0>(f.a, j % f.heads, j / f.heads, f.arrive, f.mtiles, f.err, f.pre, f.delay);
@@ -177,9 +178,9 @@ bool fused_qkv_attn_supported(const GemmArgs& g, const AttnArgs& a, int dtype) {
 }
 
 hipError_t fused_qkv_attn_launch(const GemmArgs& g, const AttnArgs& a, int M, int heads, int dtype, int* arrive, int* err,
-                                 hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                                 hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, int* arrive_prod) {
     FusedArgs f;
-    f.g = g; f.a = a; f.arrive = arrive; f.err = err;
+    f.g = g; f.a = a; f.arrive = arrive; f.err = err; f.arrive_prod = arrive_prod ? arrive_prod : arrive;
     f.nblk = g.N / 16; f.mtiles = (M + 31) / 32; f.heads = heads;
     f.n_gemm = f.nblk * f.mtiles;
     static const int pre_env = getenv("PTTS_FUSED_PRE") ? atoi(getenv("PTTS_FUSED_PRE")) : 2;          // experiment switches

@@ -2003,6 +2003,47 @@ def test_fused_qkv_attention_free_run_under_graph_replay_and_ragged_finish(hip):
     torch.cuda.empty_cache()
 
 
+def test_fused_launch_hand_off_failure_is_a_loud_error_not_a_hang(hip):
+    """The attention half of the fused launch waits for arrival tags of the projection half with a BOUNDED spin.  If they never come
+    (test hook PTTS_FUSED_TEST_BREAK=1: the projection half stores its tags elsewhere) the first workgroups give up after ~0.1 s,
+    the give-up is sticky - everything behind them stops waiting within ~1 ms - and the call ends in a PttsError at the next read
+    of the loop state instead of hanging the GPU or returning ids computed from a stale query."""
+    import time
+
+    from parler_tts_amd import _hip
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    cfg.decoder.num_hidden_layers = 2
+    sd = synthetic_state_dict(cfg, seed=5, never_eos=True, parts=("decoder",))
+    g = torch.Generator().manual_seed(1)
+    enc = torch.randn(4, 8, cfg.text_encoder.d_model, generator=g) * 0.3
+    prompt = torch.randint(2, 32000, (4, 6), generator=g)
+    os.environ["PTTS_FUSED_TEST_BREAK"] = "1"
+    try:
+        _models.clear()
+        torch.cuda.empty_cache()
+        model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device="cuda:0")
+        t0 = time.perf_counter()
+        with pytest.raises(_hip.PttsError, match="gave up waiting"):
+            model.generate(encoder_outputs=(enc,), prompt_input_ids=prompt, do_sample=False, max_length=60, return_raw_ids=True)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 60.0          # bounded: seconds, not the hours an unbounded or per-launch time-out would take
+        del model
+    finally:
+        del os.environ["PTTS_FUSED_TEST_BREAK"]
+        _models.clear()
+        torch.cuda.empty_cache()
+    # the same call on a fresh engine without the hook works
+    model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device="cuda:0")
+    model.generate(encoder_outputs=(enc,), prompt_input_ids=prompt, do_sample=False, max_length=20, return_raw_ids=True)
+    assert model.last_raw_ids.shape[1] == 20
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_page_attention_kernel_equals_general_kernel(hip):
     """cross-attention over a single page: one-wave kernel vs the general paged kernel (same arithmetic, other order)"""
     for name in ("tiny_greedy_ragged", "tiny_cfg"):      # padded description keys / fully masked null rows
