@@ -767,6 +767,10 @@ def main():
                 "avg_launch_us": round(prof.total_ms * 1e3 / max(prof.launches, 1), 2),
                 "avg_algo_bytes_per_launch": round(prof.algo_bytes / max(prof.launches, 1)),
                 "sampled_step_ms_eager": round(prof.step_ms / max(prof.steps, 1), 3),
+                **({"note": "this launch CONTAINS the latency-bound QKV projection (round 5: one launch instead of two).  Round 4 measured the attention "
+                            "kernel alone at 29.0 us = 0.73 of the peak; the same work as this launch does (attention + QKV projection) took 29.0 + 3.6 us "
+                            "and one more 1.5-us boundary there: compare avg_launch_us with 34.1, not with 29.0 (A/B on one box: decode loop -2.5 %, "
+                            "profiles/r05_fused_qkv_attn_bench.txt)"} if getattr(prof, "fused_launches", 0) else {}),
             },
         }
         # the weakest part of the step on the record next to the strongest: everything but the self-attention launches
