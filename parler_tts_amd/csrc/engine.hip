@@ -95,7 +95,6 @@ struct EventPair {
 struct Work {
     float *x = nullptr, *q = nullptr, *xstat = nullptr;
     void *attn_frag = nullptr, *mlp_frag = nullptr, *x_frag = nullptr, *x_frag2 = nullptr;
-    void* cross_frag = nullptr;  // decode only: output of the cross-attention half of the fused out-projection + cross-attention launch
     float* ffn_raw = nullptr;   // SwiGLU variant only: [rows][2 F] gate | up pre-activations
     int rows = 0;      // capacity (multiple of 32)
 };
@@ -166,12 +165,6 @@ struct ptts_engine {
     int* fuse_err = nullptr;
     int* fuse_blackhole = nullptr;      // PTTS_FUSED_TEST_BREAK=1: the producers' tags go here (test of the time-out path)
     size_t fuse_arrive_ints = 0;
-    // fused out-projection + cross-attention launch: its own tags, and an output buffer of its own for the cross-attention half (the
-    // out-projection workgroups of the same launch are still reading the self-attention's output from attn_frag)
-    int* fuse2_arrive = nullptr;
-    size_t fuse2_arrive_ints = 0;
-    void* cross_frag = nullptr;
-    bool fuse_out_cross = false;
     bool fuse_qkv_attn = true;          // PTTS_NO_FUSED_QKV_ATTN=1 (read per launch in fused.hip too): the two launches of rounds 1-4
     // ptts_state_snapshot / ptts_state_poll: pinned host copies of the loop state, one event per slot
     int* snap_host = nullptr;               // pinned, host-mapped: [PTTS_STATE_SLOTS][8 ints] (6 state fields, pad, sequence stamp)
@@ -375,7 +368,6 @@ Work decode_work(ptts_engine* e) {
     Work w;
     w.x = e->x; w.q = e->q; w.xstat = e->xstat; w.attn_frag = e->attn_frag; w.mlp_frag = e->mlp_frag;
     w.x_frag = e->x_frag; w.x_frag2 = e->x_frag2; w.rows = e->mtiles * 32; w.ffn_raw = e->ffn_raw;
-    w.cross_frag = e->cross_frag;
     return w;
 }
 
@@ -489,39 +481,9 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             g.out2 = wk.q; g.ldo2 = D; g.xfrag_out = next; g.xstat = wk.xstat;
             e->xf_cur = next;
         }
-        // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294): arguments first, so that the pair
-        // (out-projection with its look-ahead role, cross-attention) can go out as ONE launch where it qualifies (fused.hip)
-        bool fuse2 = false;
-        if (cross) {
-            a = AttnArgs();
-            a.q = wk.q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
-            a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS; a.bias_flag = e->cross_masked;
-            a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = wk.attn_frag; a.D = D;
-            a.no_page_kernel = e->no_page_kernel ? 1 : 0;
-            a.rows_per_utt = npos > 0 ? npos : 1;
-            if (look) {
-                a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16; a.lnfix_c1 = w.cq_f.c1; a.lnfix_c2 = w.cq_f.c2;
-                a.lnfix_eps = 1e-5f; a.lnfix_scale = scale; a.lnfix_rms = e->v_rms ? 1 : 0;
-            }
-            if (look && npos == 0 && e->dbg_stop < 0 && e->fuse_out_cross && e->fuse2_arrive && wk.cross_frag &&
-                fused2_arrive_ints(c.layers, (M + 31) / 32, D / 16) <= e->fuse2_arrive_ints) {
-                g.layer = l; g.state = e->state;          // the arrival tags carry pos + 1
-                fuse2 = fused_out_cross_supported(g, a, M, c.heads, e->dt);
-            }
-        }
-        if (fuse2) {
-            a.ofrag = wk.cross_frag;      // NOT attn_frag: the projection half of this launch is still reading the self-attention's output there
-            DBG_GATE(e);
-            STAMP_ARGS(e, g);
-            STAMP_ARGS(e, a);
-            int v = gemm_validate(g, e->dt);
-            if (v != 0) return fail(PTTS_E_INVALID, "gemm shape rejected (code %d): M=%d N=%d K=%d pro=%d epi=%d", v, g.M, g.N, g.K, g.pro, g.epi);
-            HIP_TRY(fused_out_cross_launch(g, a, M, c.heads, e->dt, e->fuse2_arrive, e->fuse_err, s));
-        } else {
-            DBG_GATE(e);
-            STAMP_ARGS(e, g);
-            PTTS_TRY(launch_gemm(e, g, s));
-        }
+        DBG_GATE(e);
+        STAMP_ARGS(e, g);
+        PTTS_TRY(launch_gemm(e, g, s));
         if (cross && !look) {
             // LN2 + cross-attention query (M:467-471)
             g = GemmArgs();
@@ -534,13 +496,22 @@ int run_layers(ptts_engine* e, hipStream_t s, bool profile, const Work& wk, int 
             PTTS_TRY(launch_gemm(e, g, s));
         }
         if (cross) {
-            if (!fuse2) {
-                DBG_GATE(e);
-                STAMP_ARGS(e, a);
-                HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
+            // cross attention over the T pre-projected encoder keys (cached at prefill, M:287-294)
+            a = AttnArgs();
+            a.q = wk.q; a.ldq = D; a.pool = make_pool(e, true); a.layer = l; a.len = e->T; a.len_from_state = 0;
+            a.state = e->state; a.bias = e->cross_bias; a.ld_bias = e->cross_blocks * PTTS_PAGE_TOKENS; a.bias_flag = e->cross_masked;
+            a.s_cap = e->cross_blocks * PTTS_PAGE_TOKENS; a.ofrag = wk.attn_frag; a.D = D;
+            a.no_page_kernel = e->no_page_kernel ? 1 : 0;
+            a.rows_per_utt = npos > 0 ? npos : 1;
+            if (look) {
+                a.lnfix_stat = wk.xstat; a.lnfix_blocks = D / 16; a.lnfix_c1 = w.cq_f.c1; a.lnfix_c2 = w.cq_f.c2;
+                a.lnfix_eps = 1e-5f; a.lnfix_scale = scale; a.lnfix_rms = e->v_rms ? 1 : 0;
             }
+            DBG_GATE(e);
+            STAMP_ARGS(e, a);
+            HIP_TRY(attn_decode_launch(a, M, c.heads, e->dt, e->dt, s));
             g = GemmArgs();
-            g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = fuse2 ? wk.cross_frag : wk.attn_frag;
+            g.W = w.co.ptr; g.N = D; g.K = D; g.M = M; g.pro = PRO_FRAG; g.xfrag = wk.attn_frag;
             g.epi = EPI_RESIDUAL; g.out = wk.x; g.ldo = D; g.xfrag_out = e->fold_ln ? e->xf_cur : nullptr;
             DBG_GATE(e);
             STAMP_ARGS(e, g);
@@ -1035,10 +1006,6 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->fuse_arrive_ints = fused_arrive_ints(cfg->layers, e->mtiles, cfg->heads) + 32;
     A(e->fuse_arrive, sizeof(int) * e->fuse_arrive_ints);          // the last 32 ints: the error word (own line)
     if (getenv("PTTS_FUSED_TEST_BREAK")) A(e->fuse_blackhole, sizeof(int) * e->fuse_arrive_ints);
-    e->fuse_out_cross = getenv("PTTS_FUSED_OUT_CROSS") != nullptr;        // experiment, OFF by default: measured slower (fused.hip)
-    e->fuse2_arrive_ints = fused2_arrive_ints(cfg->layers, e->mtiles, D / 16);
-    A(e->fuse2_arrive, sizeof(int) * e->fuse2_arrive_ints);
-    A(e->cross_frag, e->esz * rows * D);
     if (cfg->t5_layers > 0) {
         const int inner = cfg->t5_heads * cfg->t5_dkv;
         const size_t trows = ((size_t)Bm * cfg->max_desc_len + 31) / 32 * 32;
@@ -1050,8 +1017,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
 #undef A
     if (rc != PTTS_OK) { ptts_destroy(e); return rc; }
     e->fuse_err = e->fuse_arrive + e->fuse_arrive_ints - 32;
-    if (hipMemset(e->fuse_arrive, 0, sizeof(int) * e->fuse_arrive_ints) != hipSuccess ||
-        hipMemset(e->fuse2_arrive, 0, sizeof(int) * e->fuse2_arrive_ints) != hipSuccess) { ptts_destroy(e); return fail(PTTS_E_HIP, "hipMemset failed"); }
+    if (hipMemset(e->fuse_arrive, 0, sizeof(int) * e->fuse_arrive_ints) != hipSuccess) { ptts_destroy(e); return fail(PTTS_E_HIP, "hipMemset failed"); }
     // identity page tables
     std::vector<int> tab(Bm * e->self_blocks);
     for (size_t i = 0; i < tab.size(); ++i) tab[i] = (int)i;
@@ -1297,7 +1263,6 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
     // arrival tags of the fused QKV + attention launches carry pos + 1: a new call restarts pos, so the tags start from zero
     if (e->fuse_arrive) {
         HIP_TRY(hipMemsetAsync(e->fuse_arrive, 0, sizeof(int) * e->fuse_arrive_ints, s));
-        HIP_TRY(hipMemsetAsync(e->fuse2_arrive, 0, sizeof(int) * e->fuse2_arrive_ints, s));
         e->fuse_err = e->fuse_arrive + e->fuse_arrive_ints - 32;
     }
     e->B = B; e->B_eff = B_eff; e->T = T; e->P = P; e->L = L;

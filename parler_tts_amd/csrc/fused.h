@@ -14,9 +14,3 @@ bool fused_qkv_attn_supported(const GemmArgs& g, const AttnArgs& a, int dtype);
 // attention half never sees them: its bounded, sticky time-out and the error path of the call can be tested
 hipError_t fused_qkv_attn_launch(const GemmArgs& g, const AttnArgs& a, int M, int heads, int dtype, int* arrive, int* err,
                                  hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int* arrive_prod = nullptr);
-
-// Out-projection (+ look-ahead query) and cross-attention of a decode layer as ONE launch (fused.hip).  Arrival tags:
-// [layers][m-tiles][2 halves][2 roles][blocks = N / 16] ints, zeroed at every prefill.
-inline size_t fused2_arrive_ints(int layers, int mtiles, int blocks) { return (size_t)layers * mtiles * 4 * blocks; }
-bool fused_out_cross_supported(const GemmArgs& g, const AttnArgs& a, int M, int heads, int dtype);
-hipError_t fused_out_cross_launch(const GemmArgs& g, const AttnArgs& a, int M, int heads, int dtype, int* arrive, int* err, hipStream_t stream);

@@ -37,11 +37,6 @@ __device__ inline int fused_load_dword_sc1(const int* p) {
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-// three tag loads in flight together, one wait
-__device__ inline void fused_load3_dword_sc1(const int* p0, const int* p1, const int* p2, int& v0, int& v1, int& v2) {
-    asm volatile("global_load_dword %0, %3, off sc1\n\tglobal_load_dword %1, %4, off sc1\n\tglobal_load_dword %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
-}
 template <int EPL> __device__ inline void fused_load_q_sc1(const float* p, float (&q)[EPL]);
 template <> __device__ inline void fused_load_q_sc1<4>(const float* p, float (&q)[4]) {
     f32x4 a;
@@ -53,21 +48,6 @@ template <> __device__ inline void fused_load_q_sc1<8>(const float* p, float (&q
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
     q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = a[3]; q[4] = b[0]; q[5] = b[1]; q[6] = b[2]; q[7] = b[3];
-}
-
-template <int EPL> __device__ inline void fused_load_stats_q_sc1(const float* s0, const float* s1, const float* qp, float2& p0, float2& p1, float (&q)[EPL]);
-template <> __device__ inline void fused_load_stats_q_sc1<8>(const float* s0, const float* s1, const float* qp, float2& p0, float2& p1, float (&q)[8]) {
-    f32x4 a, b;
-    asm volatile("global_load_dwordx2 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
-                 "global_load_dwordx4 %3, %6, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(p0), "=&v"(p1), "=&v"(a), "=&v"(b) : "v"(s0), "v"(s1), "v"(qp) : "memory");
-    q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = a[3]; q[4] = b[0]; q[5] = b[1]; q[6] = b[2]; q[7] = b[3];
-}
-template <> __device__ inline void fused_load_stats_q_sc1<4>(const float* s0, const float* s1, const float* qp, float2& p0, float2& p1, float (&q)[4]) {
-    f32x4 a;
-    asm volatile("global_load_dwordx2 %0, %3, off sc1\n\tglobal_load_dwordx2 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(p0), "=&v"(p1), "=&v"(a) : "v"(s0), "v"(s1), "v"(qp) : "memory");
-    q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = a[3];
 }
 
 #define PTTS_GEMM_FUSED 1
@@ -83,13 +63,6 @@ template <> __device__ inline void fused_load_stats_q_sc1<4>(const float* s0, co
 #define PTTS_ATTN_H attn_h
 #define PTTS_ATTN_B attn_b
 #include "attn_device.inc"
-
-#define PTTS_PAGE_FUSED 1
-#define PTTS_PAGE_SIGNATURE __device__ __forceinline__ void page_body(AttnArgs a, int H, const int page_h, const int page_b, const int* fused_arrive, \
-                                                                      const int fused_mtiles, const int fused_blocks, int* fused_err)
-#define PTTS_PAGE_H page_h
-#define PTTS_PAGE_B page_b
-#include "attn_page_device.inc"
 
 struct FusedArgs {
     GemmArgs g;
@@ -123,36 +96,6 @@ __global__ __launch_bounds__(512) PTTS_FUSED_OCC void fused_qkv_attn_kernel(Fuse
 // exact-fit tile bursts (K / KSTEP = 8 waves x TILES): 4 = mini_v0.1 (D = 1024, bf16), 6 = BASELINE configs[4] (D = 1536), 8 = D = 2048 (or
 // D = 1024 in the fp32 mode); 0 = the guarded generic instance for every other width (134 registers: the attention workgroups
 // then join a CU only when its projection workgroup has left - correct, less overlap)
-// Out-projection (+ look-ahead cross-attention query) and cross-attention of a decode layer as ONE launch: blocks 0 .. n_gemm - 1 are the
-// half-split out-projection workgroups of both roles (gemm_device.inc, unchanged arithmetic), behind them one 8-wave workgroup per
-// (row, eight heads) of the single-page cross-attention kernel (attn_page_device.inc, one wave per head).  A cross-attention wave
-// requests its fold constants, the page's K / V tiles and the mask at once - all older than the launch - and waits for the arrival
-// tags of the 64 + 4 projection workgroups whose statistics / query blocks it reads.  What goes away: the boundary between the two
-// launches and the cross-attention's start-up and load latency (its ~3.5 us are mostly latency).  Bit-identical to the two launches.
-// EXPERIMENT, OFF BY DEFAULT (`PTTS_FUSED_OUT_CROSS=1`): built, parity-green, and measured SLOWER than the two launches - decode pass
-// +4.4 % with every wave polling its own tags (256 pollers per tag line), +2.5 % with one polling wave per workgroup, +2.3 % with the
-// statistics and the query in one round trip (profiles/r05_fused_qkv_attn_bench.txt).  The hand-off here is 68 producers wide and
-// there is no stream to hide it under: drained write-through stores -> tag -> poll -> loads is ~4 us of dependent fabric round
-// trips against the 1.5-us boundary + 3.5-us kernel it replaces, and the projection half shares the fabric with the pollers.
-struct Fused2Args {
-    GemmArgs g;
-    AttnArgs a;
-    int* arrive;
-    int* err;
-    int n_gemm, gx, mtiles, blocks, heads, hblocks;
-};
-
-template <typename P, int NTU>
-__global__ __launch_bounds__(512) void fused_out_cross_kernel(Fused2Args f) {
-    const int i = blockIdx.x;
-    if (i < f.n_gemm) {
-        gemm_body<P, 8, 1, false, 1, 1, false, EPI_RESIDUAL, ACT_NONE, -1, 0, false>(f.g, i % f.gx, i / f.gx, f.arrive, f.mtiles, f.blocks);
-    } else {
-        const int j = i - f.n_gemm;
-        page_body<P, P, NTU>(f.a, f.heads, (j % f.hblocks) * 8 + (int)(threadIdx.x >> 6), j / f.hblocks, f.arrive, f.mtiles, f.blocks, f.err);
-    }
-}
-
 template <typename P> int tiles_for(const GemmArgs& g) {
     const int ksteps = g.K / P::KSTEP;
     if (ksteps == 32) return 4;
@@ -212,42 +155,5 @@ hipError_t fused_qkv_attn_launch(const GemmArgs& g, const AttnArgs& a, int M, in
         }
     }
 #undef PTTS_FUSED_LAUNCH
-    return hipGetLastError();
-}
-
-bool fused_out_cross_supported(const GemmArgs& g, const AttnArgs& a, int M, int heads, int dtype) {
-    if (!getenv("PTTS_FUSED_OUT_CROSS")) return false;             // experiment switch, OFF by default (see the comment at Fused2Args)
-    // exactly the instance the unfused dispatch picks for the out-projection with its look-ahead role (gemm.hip: launch_typed)
-    if (g.fold || !g.W2 || g.wide2 || g.bias || g.rowmask || g.force_whole || g.epi != EPI_RESIDUAL || g.pro != PRO_FRAG || !g.xstat || !g.state) return false;
-    if (getenv("PTTS_GEMM_GENERIC")) return false;
-    const int kstep = dtype == PTTS_BF16 ? PBF16::KSTEP : PF32::KSTEP;
-    if (g.K % kstep != 0 || g.N > 2048 || g.N != g.N2 || g.N % 16 != 0) return false;
-    const int ksteps = g.K / kstep;
-    if (!(ksteps > 16 && ksteps <= 64)) return false;
-    // the single-page kernel with the look-ahead finish, whole groups of eight heads, rows of at most 128 blocks (two tag loads per lane)
-    if (a.no_page_kernel || a.len_from_state || a.len > PTTS_PAGE_TOKENS || a.len < 1 || !a.lnfix_stat || a.rows_per_utt != 1 || !a.state) return false;
-    if (heads % 8 != 0 || a.lnfix_blocks != g.N / 16 || a.lnfix_blocks > 128 || M < 1) return false;
-    return true;
-}
-
-hipError_t fused_out_cross_launch(const GemmArgs& g, const AttnArgs& a, int M, int heads, int dtype, int* arrive, int* err, hipStream_t stream) {
-    Fused2Args f;
-    f.g = g; f.a = a; f.arrive = arrive; f.err = err;
-    f.mtiles = (M + 31) / 32; f.blocks = g.N / 16; f.heads = heads; f.hblocks = heads / 8;
-    f.gx = ((g.N / 16 + 7) / 8) * 16 + ((g.N2 / 16 + 7) / 8) * 16;          // half-split grid of both roles (gemm.hip: launch_one)
-    f.n_gemm = f.gx * f.mtiles;
-    const size_t lds = (size_t)8 * 1 * 2 * 64 * 16;                          // K-split hand-over of the projection half; the cross half uses none
-    dim3 grid(f.n_gemm + f.hblocks * M), block(512);
-    static const bool full_page = getenv("PTTS_ATTN_PAGE_FULL") != nullptr;
-    const int tiles = full_page ? 64 : (a.len + (dtype == PTTS_BF16 ? 7 : 3)) / (dtype == PTTS_BF16 ? 8 : 4);
-#define PTTS_FUSED2_LAUNCH(P_, N1, N2)                                                                        \
-    do {                                                                                                        \
-        if (tiles <= N1) hipLaunchKernelGGL((fused_out_cross_kernel<P_, N1>), grid, block, lds, stream, f);     \
-        else if (tiles <= N2) hipLaunchKernelGGL((fused_out_cross_kernel<P_, N2>), grid, block, lds, stream, f); \
-        else hipLaunchKernelGGL((fused_out_cross_kernel<P_, 0>), grid, block, lds, stream, f);                  \
-    } while (0)
-    if (dtype == PTTS_BF16) PTTS_FUSED2_LAUNCH(PBF16, 3, 5);
-    else PTTS_FUSED2_LAUNCH(PF32, 5, 10);
-#undef PTTS_FUSED2_LAUNCH
     return hipGetLastError();
 }

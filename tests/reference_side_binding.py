@@ -1,36 +1,3 @@
-# INTEGRATION — wiring the HIP engine into danlyth/parler-tts
-
-The reference (`/root/reference`, pure Python) has no plugin/operator API for its hot path: the boundary is the Python
-method `ParlerTTSForConditionalGeneration.generate()` (`parler_tts/modeling_parler_tts.py:2342-2686`).  Two ways to adopt
-the engine, both through the same C ABI (`include/parler_tts_hip.h`, built into
-`parler_tts_amd/csrc/libparler_tts_hip.so` by `python -c "import __graft_entry__ as g; g.build()"`).
-
-## A. Drop-in import (what this repository ships)
-
-```python
-# before                                              # after
-from parler_tts import ParlerTTSForConditionalGeneration   from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
-model = ParlerTTSForConditionalGeneration.from_pretrained(ckpt_dir).to("cuda:0")      # same call; local dir, reference key layout
-audio = model.generate(input_ids=desc_ids, attention_mask=desc_mask, prompt_input_ids=prompt_ids,
-                       prompt_attention_mask=prompt_mask, do_sample=True, temperature=1.0)   # FloatTensor [B, samples]
-```
-
-`from_pretrained` reads `config.json` (reference field names: `configuration_parler_tts.py:82-127, 193-238`,
-`dac_wrapper/configuration_dac.py:8-25`), `generation_config.json` and `*.safetensors` with the reference's parameter
-names (SURVEY.md §8b), folds the codec's weight-norm pairs and hands every tensor to `ptts_load_tensor`.
-
-## B. Binding inside the reference's own class (what a maintainer of the reference would add)
-
-The reference calls `self.greedy_search(...)` / `self.sample(...)` at M:2582 / M:2608 after it has prepared
-`encoder_outputs`, `prompt_hidden_states`, the start ids and the delay-pattern mask.  A `ctypes` stub replacing those two
-calls (and the per-step `forward`) is the whole integration surface.  The block below IS `tests/reference_side_binding.py`
-(`tests/test_abi.py::test_integration_md_quotes_the_executed_binding` holds the two byte for byte) and that file is EXECUTED
-on the GPU by `tests/test_gpu_reference_binding.py`: it imports nothing of `parler_tts_amd`, takes the ABI version from
-`ptts_abi_version()`, and must return the raw ids of fixtures the real reference wrote (`tiny_greedy`, `tiny_greedy_ragged`,
-`tiny_cfg`), decode / encode the codec fixtures, and fold descript's weight-norm pairs itself.
-
-<!-- BEGIN tests/reference_side_binding.py -->
-```python
 # parler_tts/hip_backend.py  (reference side) - the binding a maintainer of danlyth/parler-tts would add.
 # ctypes over include/parler_tts_hip.h ONLY: nothing of parler_tts_amd is imported here.  `model` is the reference's own
 # ParlerTTSForConditionalGeneration (anything with .state_dict(), .config, .decoder.config, .text_encoder.config does).
@@ -196,59 +163,3 @@ class HipDecoder:
             torch.cuda.synchronize(self.device)
             _ck(_lib.ptts_dac_encode(self.h, B, T, _p(x), _p(codes), None))
         return codes[None]
-```
-<!-- END tests/reference_side_binding.py -->
-
-and in `generate()` (M:2574-2620) the two third-party calls become
-`outputs = self._hip.run(model_kwargs["encoder_outputs"][0], model_kwargs["attention_mask"], prompt_input_ids,
-model_kwargs.get("prompt_attention_mask"), model_kwargs["decoder_delay_pattern_mask"], input_ids, generation_config.max_length, ...)`.
-Everything before (M:2416-2541) and after (M:2628-2686) stays as it is; `encoder_outputs` is passed *unprojected* (the
-engine applies `enc_to_dec_proj` and the mask multiply itself, once, instead of every step as M:2010-2017 does).
-
-## C. Entry points ↔ reference code they replace
-
-| C ABI | replaces |
-|---|---|
-| `ptts_create / ptts_destroy` | module construction M:1560-1660 (decoder part), KV cache type M:611-621 |
-| `ptts_load_tensor / ptts_weights_ready` | `nn.Module` parameter ownership, `from_pretrained` M:1701-1720 |
-| `ptts_t5_encode` | `_prepare_text_encoder_kwargs_for_generation` M:2197-2241 → `T5EncoderModel` (M:2229) |
-| `ptts_dac_decode` | `DACModel.decode` D:98-134 (`quantizer.from_codes` + `DAC.decode`), called at M:2660 and M:2671 |
-| `ptts_dac_encode` | `DACModel.encode` D:25-96 (descript `DAC.encode`: encoder conv stack + residual vector quantiser), called for audio prompts at M:2276 (`_prepare_audio_encoder_kwargs_for_generation` M:2247-2292, reached from M:2483-2487) |
-| `ptts_set_decoder_mask` | `decoder_attention_mask` over the decoder prefix: concatenated behind `prompt_attention_mask` M:845-846, 4-D causal mask M:870-872, start column added at M:2186-2193 |
-| `ptts_set_prompt_embeds` | user-supplied `prompt_hidden_states` taking the place of `embed_prompts(prompt_input_ids)` M:2476-2480, M:839-840 |
-| `ptts_prefill` | `enc_to_dec_proj` + mask M:2010-2017, cross K/V M:295-298, `embed_prompts` M:2243-2245, first `forward` over the prompt M:794-978: every prompt / prefix position of a chunk as rows of one batched pass (causal mask M:870-872); `T = 0` = no encoder states (decoder-only driver, no cross-attention block M:465) |
-| `ptts_decode_steps` | the loop at M:2582 / M:2608: `prepare_inputs_for_generation` M:2081-2148, `forward` M:1927-2079 → M:794-978 → M:1096-1185, argmax / warpers+multinomial, pad-out, EOS latch, `MaxLengthCriteria` |
-| `ptts_forward_step / ptts_select_step` | the same loop body split where the third-party loop applies user `LogitsProcessor`s (`logits_processor(input_ids, next_token_logits)`, list built at M:2561-2567) |
-| `ptts_get_state`, `ptts_state_snapshot` / `ptts_state_poll` (v8) | `unfinished_sequences.max() == 0` host check of the third-party loop (called at M:2582 / M:2608): the blocking read, and its pipelined form - a one-thread kernel copies the loop state into pinned host-mapped memory behind the queued steps, the host watches a stamp; `generate()` polls every 16 steps one chunk behind (at most 31 steps past the last column, the stream never drains) |
-| `ptts_sampling.eos_token_id / pad_token_id / eos_free_until` | `generation_config.eos_token_id / pad_token_id` as the third-party loop uses them; `MinLengthLogitsProcessor` / `MinNewTokensLengthLogitsProcessor` added by `_get_logits_processor` (called at M:2561-2567) |
-| `ptts_profile_read`, `ptts_debug_*`, `ptts_set_forced_tokens`, `ptts_set_forced_sequence`, `ptts_set_block_table`, `ptts_last_logits`, `ptts_test_gemm`, `ptts_dac_kernel_counts` (v7: launches per codec conv kernel family, so that a parity test can assert WHICH kernels produced the waveform it compared) | measurement / test hooks, no reference counterpart |
-
-Error behaviour: every entry point returns 0 or a negative `PTTS_E_*`; `ptts_last_error()` carries the message (including
-HIP error strings); nothing throws across the ABI.  The Python layer maps them to `PttsError` and raises the reference's own
-`ValueError`s for the conditions the reference checks (M:2517-2521, 2575-2579, 2622-2626, D:127-128).
-
-## D. Host-side pieces that stay Python (no ABI involved)
-
-* `num_return_sequences > 1`: the reference expands ids, kwargs and the stashed delay pattern with the third-party
-  `_expand_inputs_for_generation` (M:2600-2606); the engine takes any pattern matrix, so a reference-side integration keeps
-  that call unchanged and hands the expanded tensors to `HipDecoder.run`.
-* Streaming: the reference's streamer protocol (M:2540-2541) is served by `put()` calls from the host loop;
-  `parler_tts_amd.AudioStreamer` additionally turns the id columns into audio chunks through `ptts_dac_decode` on windows with
-  the codec's receptive field as context.
-* Multi-GPU: `parler_tts_amd.distributed.generate_data_parallel(local_generate, input_ids=..., ...)` - scatter of the id slices,
-  local `generate()`, gather with per-row lengths (returns `(tensor, lengths)`) over `torch.distributed` (RCCL); nothing inside the token loop.
-  It is what the reference's evaluation loop does with `accelerator.pad_across_processes` + `gather_for_metrics`
-  (`training/run_parler_tts_training.py:1555, 1684-1689`); a reference-side integration keeps those two calls and only swaps the
-  `generate()` they wrap.  One process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
-  your_script.py`, or `python bench.py --gpus 8`, which starts that launcher itself.  Every collective of the path has run on RCCL
-  (`tests/test_gpu_distributed.py`, world size 1 on one card).
-
-## E. Decoder-op variants (ABI v7, `ptts_config.dec_variant`) - extensions, not part of the drop-in contract
-
-`ParlerTTSDecoderConfig(norm_type="rms_norm" | position_embedding="rope" | mlp_type="swiglu")` (any combination; defaults =
-the reference's LayerNorm / sinusoids / GELU) selects RMSNorm, rotary positions on the self-attention and a gated-SiLU MLP
-for random-init scaled-decoder studies (BASELINE configs[4]).  The reference's decoder has none of these ops and no switch
-for them (`modeling_parler_tts.py:402-413, 181-223, 488-490`): a checkpoint of the reference never sets these fields and loads
-exactly as before.  State-dict additions: `decoder.model.decoder.layers.{l}.fc1_up.weight [ffn, hidden]` (SwiGLU); the
-`*.layer_norm.bias` tensors are accepted and ignored under RMSNorm; rotary tables are built by the host
-(`parler_tts_amd.weights.rope_tables`) and handed over as `decoder.rope.cos` / `decoder.rope.sin`.

@@ -194,3 +194,38 @@ def test_dac_kernel_counts_hook_answers_without_a_gpu(built_lib):
     import ctypes as C
 
     assert _hip.load_library().ptts_dac_kernel_counts(None, 0, 0) == -1
+
+
+def test_integration_md_quotes_the_executed_binding():
+    """INTEGRATION.md section B shows the reference-side ctypes binding; the block must be tests/reference_side_binding.py byte
+    for byte - the file tests/test_gpu_reference_binding.py executes on the GPU - and must not pin an ABI version literal."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"<!-- BEGIN tests/reference_side_binding.py -->\n```python\n(.*?)```\n<!-- END tests/reference_side_binding.py -->",
+                  doc, flags=re.S)
+    assert m, "INTEGRATION.md lost the quoted binding"
+    src = open(os.path.join(ROOT, "tests", "reference_side_binding.py")).read()
+    assert m.group(1) == src
+    assert "ptts_abi_version()" in src and not re.search(r"PttsConfig\(\s*\d", src)
+    assert not re.search(r"^\s*(from|import)\s+parler_tts_amd", src, flags=re.M)
+    # every entry point the binding calls is declared in the header
+    used = set(re.findall(r"_lib\.(ptts_[a-z0-9_]+)", src))
+    assert used and used <= set(header_symbols())
+
+
+def test_reference_side_binding_structs_match_the_header_layout(built_lib, monkeypatch):
+    """the binding file declares its own ctypes structures (it must not import parler_tts_amd): same fields, offsets and sizes as
+    the repo's binding, which test_header_and_binding_agree / the GPU suite hold against the header"""
+    import ctypes as C
+    import importlib
+    import sys
+
+    from parler_tts_amd import _hip
+
+    monkeypatch.setenv("PTTS_HIP_LIB", built_lib)
+    sys.modules.pop("tests.reference_side_binding", None)
+    rb = importlib.import_module("tests.reference_side_binding")
+    for mine, theirs in ((_hip.PttsConfig, rb.PttsConfig), (_hip.PttsSampling, rb.PttsSampling), (_hip.PttsState, rb.PttsState)):
+        assert C.sizeof(mine) == C.sizeof(theirs)
+        assert [(n, getattr(mine, n).offset, getattr(mine, n).size) for n, *_ in mine._fields_] == \
+               [(n, getattr(theirs, n).offset, getattr(theirs, n).size) for n, *_ in theirs._fields_]
+    assert rb._lib.ptts_abi_version() == _hip.ABI_VERSION
