@@ -226,7 +226,7 @@ def make_one_pass(model, cfg, desc, amask, prompt, kw, dist, rank, world, dev, c
     return one_pass
 
 
-def dp_report(dist, world, coll_dev, phase, timings, steps, value, root=ROOT):
+def dp_report(dist, world, coll_dev, phase, timings, steps, value, root=ROOT, affinity=None):
     """What makes an N > 1 line checkable: the rank count the process group really has, the backend, min / max over ranks of
     the per-pass phases (all-gathered), and the weak-scaling efficiency against the newest single-GPU record on disk."""
     mine = torch.tensor([phase["t5_prefill_ms"] / steps, phase["decode_ms"] / steps, phase["post_ms"] / steps,
@@ -239,6 +239,14 @@ def dp_report(dist, world, coll_dev, phase, timings, steps, value, root=ROOT):
     rep = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
            "per_rank_min_max": {n: [round(float(m[:, i].min()), 2), round(float(m[:, i].max()), 2)] for i, n in enumerate(names)},
            "slowest_rank_by_decode": int(m[:, 1].argmax())}
+    # what decides the weak-scaling efficiency: how far the ranks' local generate() times lie apart, and where
+    # each rank's host loop was allowed to run
+    gen = m[:, 4]
+    rep["generate_ms_last_pass_by_rank"] = [round(float(x), 2) for x in gen]
+    rep["generate_ms_spread_pct"] = round(float((gen.max() - gen.min()) / gen.min() * 100.0), 3) if float(gen.min()) > 0 else None
+    masks = [None] * world
+    dist.all_gather_object(masks, affinity)
+    rep["affinity_by_rank"] = masks
     n1, src = None, None
     import glob
     for path in sorted(glob.glob(os.path.join(root, "BENCH_r*.json")), reverse=True) + [os.path.join(root, "profiles", "r04_bench_default.json")]:
@@ -606,6 +614,16 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     plumbing = args.plumbing_only
+    # a rank of a multi-rank run binds itself to the cores next to ITS GPU before anything touches the card (the pass is as fast as
+    # its slowest rank, and a rank's speed is its host loop's: parler_tts_amd/affinity.py; PTTS_NO_AFFINITY=1 opts out).  N = 1 is
+    # left alone: nothing to be slower than, and the CPU baseline of the same process wants every core.
+    affinity = None
+    if world > 1:
+        from parler_tts_amd.affinity import bind_rank_to_numa_node
+
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        affinity = bind_rank_to_numa_node(local_rank, local_world,
+                                          gpu_of_slot=[0] * local_world if os.environ.get("PTTS_SHARE_GPU") else None)
     dist = None
     if world > 1 or args.force_dp:
         import torch.distributed as dist
@@ -703,7 +721,8 @@ def main():
     F = L - K
     audio_s = B * F / cfg.audio_encoder.frame_rate * args.steps * world
     prof = model.engine().profile_read(reset=True)
-    dp = dp_report(dist, world, coll_dev, phase, timings, args.steps, 0.0 if plumbing else tokens / dt) if dist is not None else None
+    dp = dp_report(dist, world, coll_dev, phase, timings, args.steps, 0.0 if plumbing else tokens / dt, affinity=affinity) \
+        if dist is not None else None
     if dp is not None and world > 1 and rank == 0 and out is not None:
         # SURVEY section 4 test (5) inside the N > 1 line: ONE extra, untimed generate() of rank 1's slice on
         # rank 0's own GPU; the codec ids the data-parallel pass gathered for that slice must be the ids one GPU computes for it

@@ -171,7 +171,17 @@ typedef struct ptts_sampling {
  *      (M:1927-2079 -> M:794-978 -> M:1096-1185), token selection, pad-out of finished rows, EOS
  *      latch}.  State stays on the device; steps are replayed from a captured hipGraph.
  *      profile_every > 0: every profile_every-th step is launched eagerly with HIP events around the
- *      self-attention kernels (read back with ptts_profile_read). ---- */
+ *      self-attention kernels (read back with ptts_profile_read).
+ *      REQUIRED after the last ptts_decode_steps / ptts_select_step of a call and BEFORE raw_ids (or anything derived from
+ *      them) is used: one read of the loop state - ptts_get_state, or a ptts_state_snapshot taken behind the last step and
+ *      polled.  That read is where an error of the work already queued surfaces: these calls only enqueue, and a decode layer's
+ *      QKV projection + self-attention run as ONE launch whose attention half waits for the projection half through in-grid
+ *      arrival tags with a bounded (2 s of device wall time), sticky wait - if it ever gives up, the step used a stale query,
+ *      the error word is set, and ptts_get_state / ptts_state_poll return PTTS_E_HIP ("gave up waiting ... results invalid").
+ *      Invariant behind those tags (enforced here, stated for completeness): a tag is the cache position + 1, so every pass over
+ *      the layers must run at a position of its own within one ptts_prefill .. decode sequence - ptts_decode_steps clamps n_steps
+ *      to the columns left, ptts_forward_step refuses a second forward half before its ptts_select_step and at max_length, and
+ *      ptts_prefill clears the tags. ---- */
 int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, int32_t profile_every, void* stream);
 
 /* One decode step in two halves, for callers that edit the scores in between (custom LogitsProcessor lists,
@@ -186,7 +196,8 @@ int ptts_forward_step(ptts_engine* e, void* stream);
 int ptts_select_step(ptts_engine* e, const ptts_sampling* sp, void* stream);
 
 /* Loop state (host copy; synchronises `stream`): cur_len, unfinished rows, the column count at which
- * every row had finished (0 = not yet), steps run. */
+ * every row had finished (0 = not yet), steps run.  Also the point where a failed in-grid hand-off of the queued steps is
+ * reported (PTTS_E_HIP; see ptts_decode_steps): every caller reads it once behind its last step. */
 typedef struct ptts_state {
     int32_t pos, cur_len, prompt_len, n_unfinished, done_len, step_count;
 } ptts_state;

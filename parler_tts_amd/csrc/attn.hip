@@ -257,16 +257,12 @@ hipError_t attn_decode_launch(const AttnArgs& a, int B, int H, int cache_dtype, 
     }
     size_t lds = ((size_t)a.s_cap + NWAVES * 64 + NWAVES + a.pool.max_blocks + 64) * sizeof(float);   // + 64: look-ahead q
     dim3 grid(H, B), block(NWAVES * 64);
-    // the compile-time specialised instance is an experiment switch (PTTS_ATTN_SPEC=1): smaller code, no taken branches over
-    // the unused blocks - and measured SLOWER (decode pass 3586 -> 3609 ms, 29.0 -> 29.3 us per launch), so the generic one stays
-    const bool spec = a.pool.block_table == nullptr && !a.lnfix_qkv && getenv("PTTS_ATTN_SPEC") != nullptr;
+    // (a compile-time specialised instance - identity table, no look-ahead prologue - measured SLOWER in round 4: decode pass
+    // 3586 -> 3609 ms, 29.0 -> 29.3 us per launch; deleted in round 6)
 #define PTTS_ATTN_LAUNCH(P_, O_)                                                                             \
     do {                                                                                                     \
         /* profiled launches: events bound to THIS dispatch (its own start / end timestamps, no barrier packets) */ \
-        if (spec && ev_start && a.len_from_state)                                                            \
-            hipExtLaunchKernelGGL((attn_decode_kernel<P_, O_, true, 1>), grid, block, (uint32_t)lds, stream, ev_start, ev_stop, 0, a); \
-        else if (spec && a.len_from_state) hipLaunchKernelGGL((attn_decode_kernel<P_, O_, true, 1>), grid, block, lds, stream, a); \
-        else if (ev_start && a.len_from_state)                                                               \
+        if (ev_start && a.len_from_state)                                                               \
             hipExtLaunchKernelGGL((attn_decode_kernel<P_, O_, true>), grid, block, (uint32_t)lds, stream, ev_start, ev_stop, 0, a); \
         else if (ev_start)                                                                                   \
             hipExtLaunchKernelGGL((attn_decode_kernel<P_, O_, false>), grid, block, (uint32_t)lds, stream, ev_start, ev_stop, 0, a); \

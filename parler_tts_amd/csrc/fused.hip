@@ -58,8 +58,9 @@ template <> __device__ inline void fused_load_q_sc1<8>(const float* p, float (&q
 #include "gemm_device.inc"
 
 #define PTTS_ATTN_FUSED 1
+#define PTTS_FUSED_GIVE_UP_TICKS 200000000ull      // s_memrealtime ticks (100 MHz): 2 s
 #define PTTS_ATTN_SIGNATURE __device__ __forceinline__ void attn_body(AttnArgs a, const int attn_h, const int attn_b, const int* fused_arrive, \
-                                                                      const int fused_mtiles, int* fused_err, const int fused_pre, const int fused_delay)
+                                                                      const int fused_mtiles, int* fused_err, const int fused_pre)
 #define PTTS_ATTN_H attn_h
 #define PTTS_ATTN_B attn_b
 #include "attn_device.inc"
@@ -71,7 +72,7 @@ struct FusedArgs {
     int* arrive_prod;                  // where the projection half stores its tags: = arrive (a test hook points it elsewhere: the attention half then times out)
     int* err;
     int n_gemm, nblk, mtiles, heads;
-    int pre, delay;                    // early K bursts per attention workgroup (0 .. 2) and s_sleep(16) units in front of them
+    int pre;                           // early K bursts per attention workgroup (0 .. 2)
 };
 
 // diagnostic build only: the in-kernel stamps cost 16 registers (84 instead of 68: two workgroups per CU instead of three, i.e. a third
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(512) PTTS_FUSED_OCC void fused_qkv_attn_kernel(Fuse
         gemm_body<P, 8, 1, false, 1, 2, true, EPI_QKV_SELF, ACT_NONE, 0, TILES, false>(f.g, i % f.nblk, i / f.nblk, f.arrive_prod, f.mtiles, f.heads);
     } else {
         const int j = i - f.n_gemm;
-        attn_body<P, P, true, 0>(f.a, j % f.heads, j / f.heads, f.arrive, f.mtiles, f.err, f.pre, f.delay);
+        attn_body<P, P, true>(f.a, j % f.heads, j / f.heads, f.arrive, f.mtiles, f.err, f.pre);
     }
 }
 
@@ -107,7 +108,12 @@ template <typename P> int tiles_for(const GemmArgs& g) {
 }  // namespace
 
 bool fused_qkv_attn_supported(const GemmArgs& g, const AttnArgs& a, int dtype) {
-    if (getenv("PTTS_NO_FUSED_QKV_ATTN")) return false;            // A/B and the bit-identity tests
+    // (PTTS_NO_FUSED_QKV_ATTN=1 - A/B and the bit-identity tests - is read once, at engine creation: ptts_engine::fuse_qkv_attn)
+    // PTTS_GEMM_GENERIC=1 sends the unfused projection to the generic instance: the pair is then two launches as well, so that the
+    // switch changes every projection of the step and not all but this one
+    // (read per call like gemm.hip's own test of it - eager launches and graph capture only, never a replayed step - because the
+    // bit-identity test flips it inside one process)
+    if (getenv("PTTS_GEMM_GENERIC")) return false;
     if (!g.fold || g.W2 || g.bias || g.rowmask || g.force_whole || g.rope_k || g.npos != 0 || g.epi != EPI_QKV_SELF || g.pro != PRO_FRAG) return false;
     if (g.N != 3 * g.D || g.D % 64 != 0 || g.M < 1) return false;
     if (a.pool.block_table || a.lnfix_qkv || !a.len_from_state || a.rows_per_utt != 1 || a.npos != 0) return false;
@@ -127,8 +133,7 @@ hipError_t fused_qkv_attn_launch(const GemmArgs& g, const AttnArgs& a, int M, in
     f.nblk = g.N / 16; f.mtiles = (M + 31) / 32; f.heads = heads;
     f.n_gemm = f.nblk * f.mtiles;
     static const int pre_env = getenv("PTTS_FUSED_PRE") ? atoi(getenv("PTTS_FUSED_PRE")) : 2;          // experiment switches
-    static const int delay_env = getenv("PTTS_FUSED_DELAY") ? atoi(getenv("PTTS_FUSED_DELAY")) : 0;
-    f.pre = pre_env; f.delay = delay_env;
+    f.pre = pre_env;
     // dynamic LDS: the larger of the two halves (K-split hand-over + statistics of the projection; scores + partial outputs of the attention)
     const size_t lds_g = (size_t)8 * 1 * 2 * 64 * 16 + (size_t)8 * 2 * 2 * 16 * 4;
     const size_t lds_a = ((size_t)a.s_cap + 8 * 64 + 8 + a.pool.max_blocks + 64) * sizeof(float);

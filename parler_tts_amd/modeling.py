@@ -299,14 +299,24 @@ class HipEngine:
 _hiprt = None
 
 
+_side_streams: Dict[int, "torch.cuda.ExternalStream"] = {}
+
+
 def _own_stream(device: torch.device) -> "torch.cuda.ExternalStream":
-    """ONE non-blocking HIP stream, created directly and handed to torch as an ExternalStream (`torch.cuda.Stream()` draws from
-    torch's pool, which creates 32 streams per priority level on first use; the engine needs one queue, not 64).
+    """ONE non-blocking HIP stream PER DEVICE AND PROCESS, created directly and handed to torch as an ExternalStream
+    (`torch.cuda.Stream()` draws from torch's pool, which creates 32 streams per priority level on first use; the engine needs
+    one queue, not 64).  Shared by every model of the process on that device and never destroyed: a raw stream per model was
+    leaked at `model.to(device)` / model deletion, and destroying one under torch's caching allocator - which keys
+    its free blocks by stream - is not safe.  generate() is host-driven and not thread-safe per engine, so models on one device
+    share the queue without losing anything.
     Note for SHARED cards (several processes on one GPU - not the deployment, one process per GPU is): a process that keeps its
     queue full through this stream shares badly - the 2-rank shared-GPU rehearsal of the benchmark takes 14.9-18.0 s per pass
     against 6.2 s on the host-synchronous NULL-stream path, which drains the queue every few steps.  `PTTS_NO_SIDE_STREAM=1`
     selects that path (bench.py sets it under PTTS_SHARE_GPU)."""
     global _hiprt
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _side_streams:
+        return _side_streams[idx]
     if _hiprt is None:
         _hiprt = C.CDLL("libamdhip64.so")
         _hiprt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -318,7 +328,8 @@ def _own_stream(device: torch.device) -> "torch.cuda.ExternalStream":
         rc = _hiprt.hipStreamCreateWithFlags(C.byref(h), 1)        # hipStreamNonBlocking
     if rc != 0 or not h.value:
         raise RuntimeError(f"hipStreamCreateWithFlags failed: {rc}")
-    return torch.cuda.ExternalStream(h.value, device=device)
+    _side_streams[idx] = torch.cuda.ExternalStream(h.value, device=device)
+    return _side_streams[idx]
 
 
 def _hipMemcpyDtoD(dst: int, src: int, nbytes: int) -> int:
@@ -921,7 +932,13 @@ class ParlerTTSForConditionalGeneration:
                 L_out = st.done_len
         if streamer is not None:
             streamer.end()
-        torch.cuda.current_stream().synchronize()
+        # ONE blocking read of the loop state behind the last step, on every path (it is also the synchronisation this point
+        # needs): it is what turns a failed in-grid hand-off of the fused launch into a PttsError BEFORE any id is used.  Without
+        # it a call with no streamer and no EOS criterion (or under PTTS_LEGACY_POLL) never looked at the error word and would
+        # have returned ids computed from a stale query.
+        st_end = eng.state()
+        if st_end.done_len and st_end.done_len < L_out:
+            L_out = st_end.done_len
         t_post = _tick()
         if self.phase_times is not None:
             self.phase_times["t5_prefill_ms"] += (t_dec - t_start) * 1e3

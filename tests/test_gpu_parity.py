@@ -1946,9 +1946,7 @@ def test_fused_qkv_attention_launch_equals_the_two_launches_bit_for_bit(hip):
             for B, P in ((32, 16), (19, 70), (40, 5)):
                 got, want, _, _ = _oracle_vs_engine(cfg, sd, dtype, B=B, T=40, P=P, L=10, seed=8, steps=8)
                 assert (got - want).abs().max() < (0.1 if dtype == "bf16" else 5e-4)
-                # ... and with the out-projection (+ look-ahead query) + cross-attention pair fused the same way (PTTS_FUSED_OUT_CROSS=1:
-                # an experiment that is OFF by default - parity-green, measured slower; csrc/fused.hip)
-                for off in (("PTTS_NO_FUSED_QKV_ATTN",), ("PTTS_FUSED_OUT_CROSS",), ("PTTS_NO_FUSED_QKV_ATTN", "PTTS_FUSED_OUT_CROSS")):
+                for off in (("PTTS_NO_FUSED_QKV_ATTN",),):
                     for k in off:
                         os.environ[k] = "1"
                     try:
@@ -2005,9 +2003,11 @@ def test_fused_qkv_attention_free_run_under_graph_replay_and_ragged_finish(hip):
 
 def test_fused_launch_hand_off_failure_is_a_loud_error_not_a_hang(hip):
     """The attention half of the fused launch waits for arrival tags of the projection half with a BOUNDED spin.  If they never come
-    (test hook PTTS_FUSED_TEST_BREAK=1: the projection half stores its tags elsewhere) the first workgroups give up after ~0.1 s,
-    the give-up is sticky - everything behind them stops waiting within ~1 ms - and the call ends in a PttsError at the next read
-    of the loop state instead of hanging the GPU or returning ids computed from a stale query."""
+    (test hook PTTS_FUSED_TEST_BREAK=1: the projection half stores its tags elsewhere) the first workgroups give up after 2 s of
+    device wall time, the give-up is sticky - everything behind them stops waiting within ~1 ms - and the call ends in a PttsError
+    at the next read of the loop state instead of hanging the GPU or returning ids computed from a stale query.  EVERY way through
+    generate() reads that state before it hands out ids: the pipelined EOS poll, a call with NO EOS criterion (which
+    polls nothing on the way), a streamer, and the step-wise path of user logits processors."""
     import time
 
     from parler_tts_amd import _hip
@@ -2026,11 +2026,27 @@ def test_fused_launch_hand_off_failure_is_a_loud_error_not_a_hang(hip):
         _models.clear()
         torch.cuda.empty_cache()
         model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device="cuda:0")
-        t0 = time.perf_counter()
-        with pytest.raises(_hip.PttsError, match="gave up waiting"):
-            model.generate(encoder_outputs=(enc,), prompt_input_ids=prompt, do_sample=False, max_length=60, return_raw_ids=True)
-        torch.cuda.synchronize()
-        assert time.perf_counter() - t0 < 60.0          # bounded: seconds, not the hours an unbounded or per-launch time-out would take
+        from parler_tts_amd import AudioStreamer  # noqa: F401  (the streamer protocol: put / end)
+
+        class _Sink:
+            poll_steps = 4
+
+            def __init__(self):
+                self.cols = 0
+
+            def put(self, v):
+                self.cols += 1
+
+            def end(self):
+                pass
+
+        for kw in (dict(), dict(eos_token_id=None), dict(streamer=_Sink()), dict(logits_processor=[lambda ids, sc: sc])):
+            t0 = time.perf_counter()
+            with pytest.raises(_hip.PttsError, match="gave up waiting"):
+                model.generate(encoder_outputs=(enc,), prompt_input_ids=prompt, do_sample=False, max_length=60, return_raw_ids=True, **kw)
+            torch.cuda.synchronize()
+            # bounded: seconds, not the hours an unbounded or per-launch time-out would take
+            assert time.perf_counter() - t0 < 60.0, (list(kw), time.perf_counter() - t0)
         del model
     finally:
         del os.environ["PTTS_FUSED_TEST_BREAK"]
