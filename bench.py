@@ -51,6 +51,27 @@ def decode_loop_roofline(dec, B, T, P, n_steps, esz, seconds):
             "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 
+def t5_prefill_flops(cfg, B, T, P):
+    """Matrix-product flops of the one-off MFMA phases in front of the token loop ("Prefill, T5 encoder, DAC decode = MFMA,
+    reported separately as achieved TFLOP/s vs gfx950 peak"): what the engine EXECUTES - T5 encoder stack, enc_to_dec_proj, the cross
+    K / V projections of every decoder layer, the decoder layers over the P prompt positions (no LM heads: nothing is sampled for a
+    prompt position) - counted from the configuration, with SURVEY 8d's own closed forms next to it."""
+    t5, dec = cfg.text_encoder, cfg.decoder
+    d, inner, ff = t5.d_model, t5.num_heads * t5.d_kv, t5.d_ff
+    gated = 2 if getattr(t5, "is_gated_act", str(getattr(t5, "feed_forward_proj", "")).startswith("gated")) else 1
+    t5_mm = 2.0 * B * T * t5.num_layers * (3 * inner * d + inner * d + gated * d * ff + ff * d)
+    t5_attn = 4.0 * B * t5.num_heads * T * T * t5.d_kv * t5.num_layers
+    D, L, F = dec.hidden_size, dec.num_hidden_layers, dec.ffn_dim
+    enc_proj = 2.0 * B * T * d * D if d != D else 0.0
+    cross_kv = 2.0 * (2 * D * D) * L * B * T
+    layers = 2.0 * B * P * L * (6 * D * D + 2 * D * F)
+    attn = 4.0 * B * P * L * D * ((P + 1) / 2.0 + T)
+    n_dec = L * (6 * D * D + 2 * D * F + 6 * D) + 2 * D + dec.num_codebooks * dec.vocab_size * D
+    survey = 2.0 * 110e6 * B * T + 2.0 * n_dec * B * (P + 1) + cross_kv
+    return {"t5": t5_mm + t5_attn, "enc_proj_cross_kv": enc_proj + cross_kv, "prefill_layers": layers + attn,
+            "total": t5_mm + t5_attn + enc_proj + cross_kv + layers + attn, "survey_8d_closed_form": survey}
+
+
 def synth_inputs(cfg, B, T, P, seed):
     g = torch.Generator().manual_seed(seed)
     desc = torch.randint(2, min(32100, cfg.text_encoder.vocab_size), (B, T), generator=g)
@@ -775,6 +796,18 @@ def main():
                 "tflops_fp32_equivalent": round(1.61e9 * B * F / (phase["post_ms"] / args.steps / 1e3) / 1e12, 1),
                 "mfma_fp16_tflops": round(3 * 1.61e9 * B * F / (phase["post_ms"] / args.steps / 1e3) / 1e12, 1),
                 "frac_of_fp16_dense_peak_2500": round(3 * 1.61e9 * B * F / (phase["post_ms"] / args.steps / 1e3) / 1e12 / 2500.0, 3)},
+            # the other MFMA phase: T5 encoder + enc_to_dec_proj + cross K / V + batched prefill, as executed flops over the
+            # measured phase time (which also holds the phase's launch overhead and host synchronisations) against the dense bf16 peak
+            "t5_prefill_rank0": None if (plumbing or not phase["t5_prefill_ms"]) else (lambda fl, ms: {
+                "gflop": round(fl["total"] / 1e9, 1), "gflop_t5": round(fl["t5"] / 1e9, 1),
+                "gflop_enc_proj_cross_kv": round(fl["enc_proj_cross_kv"] / 1e9, 1), "gflop_prefill_layers": round(fl["prefill_layers"] / 1e9, 1),
+                "gflop_survey_8d_closed_form": round(fl["survey_8d_closed_form"] / 1e9, 1), "ms": round(ms, 3),
+                "tflops": round(fl["total"] / 1e12 / (ms / 1e3), 1),
+                "frac_of_bf16_dense_peak_2500": round(fl["total"] / 1e12 / (ms / 1e3) / 2500.0, 4),
+                "kernel": "gemm_tile_kernel (csrc/gemm_tile.hip: 128 x 128 MFMA tiles, operands by LDS-DMA) for every product of >= 128 rows in the "
+                          "bf16 mode; PTTS_PREFILL_M128=0 = the 32-row decode kernels of rounds 1-5 (12.4 ms, 0.026 of the peak on the r05 record)"
+                          if args.dtype == "bf16" else "gemm_kernel with M / 32 m-tiles (fp32 parity mode: 4 x v_mfma_f32_16x16x4_f32 per tile)"})(
+                t5_prefill_flops(cfg, B, T, P), phase["t5_prefill_ms"] / args.steps),
             "roofline": {
                 "kernel": ("fused_qkv_attn_kernel (csrc/fused.hip: QKV projection + self-attention over the paged KV cache in ONE launch; bytes = "
                            "the K/V rows + the QKV weights; PTTS_NO_FUSED_QKV_ATTN=1 runs the two launches of rounds 1-4)")
@@ -821,7 +854,7 @@ def main():
             line["invalid"] = "--plumbing-only: stand-in model on CPU ranks, nothing was measured" + \
                               ("; " + line["invalid"] if "invalid" in line else "")
             for k in ("rtf_audio_s_per_wall_s", "decode_loop_tokens_per_s", "ttft_ms_rank0", "decode_loop_roofline_rank0", "roofline",
-                      "dac_decode_rank0", "phase_ms_per_step_rank0"):
+                      "dac_decode_rank0", "phase_ms_per_step_rank0", "t5_prefill_rank0"):
                 line.pop(k, None)
         line["profile_every"] = args.profile_every    # every n-th decode step of the timed region runs eagerly with events
         if scaled:

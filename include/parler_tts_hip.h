@@ -268,7 +268,9 @@ int ptts_profile_read(ptts_engine* e, ptts_profile* out_host, int32_t reset);
  * reachable here, 1 = plain rows, 2 = LayerNorm (staged), 3 = T5 RMSNorm, 4 = LayerNorm through the folded path
  * (gamma folded into the weights, row statistics from the activation fragments, normalisation in the epilogue), 5 = plain
  * rows through the fragment-input path, 6 = 4 kept on the two-half workgroup where the dispatch would pick the
- * half-split grid (N <= 2048, M > 16; A/B of the two folded instances).  With PTTS_TEST_GEMM_ITERS=n in
+ * half-split grid (N <= 2048, M > 16; A/B of the two folded instances), 7 / 8 = 5 / 4 launched as the one-off phases launch
+ * them: with M >= 128 rows in the bf16 mode the product runs on the 128 x 128 MFMA tile kernel (csrc/gemm_tile.hip) that the T5
+ * encoder, the batched prefill and the cross K / V projections use.  With PTTS_TEST_GEMM_ITERS=n in
  * the environment the GEMM is relaunched n times and every result compared bitwise with the first (stderr report). */
 int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* W, const float* X, int32_t prologue,
                    const float* gamma, const float* beta, float eps, int32_t act, const float* bias, float* Y,

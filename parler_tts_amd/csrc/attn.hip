@@ -145,10 +145,15 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_causal_kernel(AttnArgs a, in
 // LDSKV = true: K and V of the (head, utterance) are parked in LDS (fits up to T ~ 300 at d_kv 64); false: they are read
 // from the fp32 QKV rows in global memory (L2-resident: T x 3 x inner floats per utterance), for descriptions up to the
 // 512 tokens T5 accepts.  Same arithmetic and summation order either way.
-template <typename OP, bool LDSKV>
+// DK > 0: the head width is a compile-time constant (64 = every T5 this engine has met), so the score and P.V loops unroll and
+// their LDS reads go out in batches.  The round-1 form (run-time dk, one dependent LDS round trip per multiply-add, the softmax
+// division repeated inside the P.V loop) took 64 us per launch at 32 x 40 tokens - 0.77 ms of the 12-layer encoder, more than its
+// GEMMs once those ran on the tile kernel.  Same arithmetic in the same order: p = e / sum is computed once per (query, key)
+// instead of once per (query, key, feature).
+template <typename OP, bool LDSKV, int DK = 0>
 __global__ __launch_bounds__(256) void attn_full_kernel(FullAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = a.T, dk = a.dk;
+    const int T = a.T, dk = DK > 0 ? DK : a.dk;
     float* ks = reinterpret_cast<float*>(smem);          // [T][dk+1]   (LDSKV only)
     float* vs = ks + (LDSKV ? T * (dk + 1) : 0);         // [T][dk+1]
     float* pr = vs + (LDSKV ? T * (dk + 1) : 0);         // [4 waves][T] probabilities of the wave's query
@@ -175,6 +180,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(FullAttnArgs a) {
         for (int j = lane; j < T; j += 64) {
             float s = 0.f;
             if (LDSKV) {
+#pragma unroll 16
                 for (int d = 0; d < dk; ++d) s = fmaf(qs[w * dk + d], ks[j * (dk + 1) + d], s);
             } else {
                 const float4* kr = reinterpret_cast<const float4*>(kg + (size_t)j * a.ld);
@@ -198,13 +204,16 @@ __global__ __launch_bounds__(256) void attn_full_kernel(FullAttnArgs a) {
             sum += e;
         }
         sum = wave_sum(sum);
+        for (int j = lane; j < T; j += 64) pr[w * T + j] = pr[w * T + j] / sum;      // the lane's own entries: no barrier needed in between
         __builtin_amdgcn_wave_barrier();
         for (int d = lane; d < dk; d += 64) {
             float o = 0.f;
             if (LDSKV) {
-                for (int j = 0; j < T; ++j) o = fmaf(pr[w * T + j] / sum, vs[j * (dk + 1) + d], o);
+#pragma unroll 8
+                for (int j = 0; j < T; ++j) o = fmaf(pr[w * T + j], vs[j * (dk + 1) + d], o);
             } else {
-                for (int j = 0; j < T; ++j) o = fmaf(pr[w * T + j] / sum, vg[(size_t)j * a.ld + d], o);   // lanes read one row: coalesced
+#pragma unroll 4
+                for (int j = 0; j < T; ++j) o = fmaf(pr[w * T + j], vg[(size_t)j * a.ld + d], o);   // lanes read one row: coalesced
             }
             int row = b * T + qi;
             typename OP::elem_t* of = reinterpret_cast<typename OP::elem_t*>(a.ofrag) + (size_t)(row >> 5) * 32 * inner;
@@ -228,6 +237,10 @@ hipError_t attn_init() {
         e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PBF16, true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PF32, true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<PF32, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -301,8 +314,13 @@ hipError_t attn_full_launch(const FullAttnArgs& a, int B, int out_dtype, hipStre
     dim3 grid(a.H, B), block(256);
     const bool force_global = getenv("PTTS_T5_GLOBAL_KV") != nullptr;      // A/B and tests of the long-description path
     if (lds <= 160 * 1024 && !force_global) {
-        if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_full_kernel<PBF16, true>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((attn_full_kernel<PF32, true>), grid, block, lds, stream, a);
+        if (a.dk == 64) {
+            if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_full_kernel<PBF16, true, 64>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((attn_full_kernel<PF32, true, 64>), grid, block, lds, stream, a);
+        } else {
+            if (out_dtype == PTTS_BF16) hipLaunchKernelGGL((attn_full_kernel<PBF16, true>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((attn_full_kernel<PF32, true>), grid, block, lds, stream, a);
+        }
         return hipGetLastError();
     }
     // K / V of this (head, utterance) exceed the LDS (T > ~300 at d_kv = 64): read them from the QKV rows in global memory

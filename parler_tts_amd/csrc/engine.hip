@@ -192,6 +192,10 @@ struct ptts_engine {
     float *t5_x = nullptr, *t5_qkv = nullptr;
     void *t5_afrag = nullptr, *t5_ffrag = nullptr;
     // per-call
+    // one-off phases (T5 encoder, batched prefill, cross K / V) in the bf16 mode: launches of >= 128 rows may take the MFMA tile kernel
+    // (gemm_tile.hip).  `oneoff` is true only while such a phase queues its launches (OneOff guard): decode steps never see it.
+    bool oneoff = false;
+    void* stage_frag = nullptr;         // fp32 rows -> bf16 fragments for those launches (T5 RMSNorm rows, the projected encoder states)
     bool prefilled = false;
     bool half_pending = false;   // ptts_forward_step ran, ptts_select_step has not yet
     int B = 0, B_eff = 0, T = 0, P = 0, L = 0;
@@ -261,11 +265,29 @@ KVPool make_pool(const ptts_engine* e, bool cross) {
     return p;
 }
 
+struct OneOff {      // scope of a one-off phase: its launches may go to the tile kernel
+    ptts_engine* e;
+    explicit OneOff(ptts_engine* e_) : e(e_) { e->oneoff = true; }
+    ~OneOff() { e->oneoff = false; }
+};
+
 int launch_gemm(ptts_engine* e, const GemmArgs& a, hipStream_t s) {
     int v = gemm_validate(a, e->dt);
     if (v != 0) return fail(PTTS_E_INVALID, "gemm shape rejected (code %d): M=%d N=%d K=%d pro=%d epi=%d", v, a.M, a.N, a.K, a.pro, a.epi);
+    if (e->oneoff) {
+        GemmArgs b = a;
+        b.tile_ok = 1;
+        HIP_TRY(gemm_launch(b, e->dt, s));
+        return PTTS_OK;
+    }
     HIP_TRY(gemm_launch(a, e->dt, s));
     return PTTS_OK;
+}
+
+// a one-off launch with a staged prologue (fp32 rows, optionally normalised) and >= 128 rows: the rows go through ONE conversion
+// pass into bf16 fragments (same arithmetic and rounding point as the staged prologue) and the product runs on the tile kernel
+bool tile_rows_path(const ptts_engine* e, int M) {
+    return e->oneoff && e->dt == PTTS_DTYPE_BF16 && e->stage_frag && M >= 128 && gemm_tile_enabled();
 }
 
 bool parse_idx(const std::string& name, const std::string& prefix, int* idx, std::string* rest) {
@@ -998,6 +1020,11 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->cross_bias, sizeof(float) * Bm * e->cross_blocks * PTTS_PAGE_TOKENS);
     A(e->cross_masked, sizeof(int) * 4);
     A(e->enc_h, sizeof(float) * ((size_t)Bm * cfg->max_desc_len + 32) * D);
+    if (e->dt == PTTS_DTYPE_BF16) {      // rows x the widest staged input (decoder width, or the T5 width when the encoder is on board)
+        const size_t srows = ((size_t)Bm * cfg->max_desc_len + 31) / 32 * 32;
+        const size_t swidth = (cfg->t5_layers > 0 && cfg->enc_hidden > D) ? cfg->enc_hidden : D;
+        A(e->stage_frag, e->esz * srows * swidth);
+    }
     A(e->tok_in, sizeof(int) * rows * K);
     A(e->unfinished, sizeof(int) * (rows * K + 32));     // + 32: the attention kernel reads 16 flags from an utterance's first one, whatever K is
     A(e->force, sizeof(long long) * rows * K);
@@ -1213,12 +1240,18 @@ int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_id
     hipStream_t s;
     PTTS_TRY(enter_stream(e, stream, &s));
     const int d = c.enc_hidden, inner = c.t5_heads * c.t5_dkv, ff = c.t5_dff, M = B * T;
+    OneOff phase(e);
+    const bool tile = tile_rows_path(e, M);
     HIP_TRY(t5_embed_launch((const long long*)input_ids, e->t5_shared, e->t5_x, M, d, e->dt, s));
     for (int l = 0; l < c.t5_layers; ++l) {
         T5Layer& w = e->t5[l];
         GemmArgs g;
         g.W = w.qkv.ptr; g.N = 3 * inner; g.K = d; g.M = M; g.pro = PRO_RMSNORM; g.x = e->t5_x; g.ldx = d;
         g.gamma = w.ln0; g.eps = c.t5_eps; g.epi = EPI_ROWMAJOR; g.out = e->t5_qkv; g.ldo = 3 * inner;
+        if (tile) {
+            HIP_TRY(rows_norm_to_frag_launch(e->t5_x, d, w.ln0, nullptr, c.t5_eps, PRO_RMSNORM, e->stage_frag, M, d, s));
+            g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = e->stage_frag;
+        }
         PTTS_TRY(launch_gemm(e, g, s));
         FullAttnArgs fa;
         fa.qkv = e->t5_qkv; fa.ld = 3 * inner; fa.T = T; fa.H = c.t5_heads; fa.dk = c.t5_dkv; fa.scale = 1.0f;
@@ -1233,6 +1266,10 @@ int ptts_t5_encode(ptts_engine* e, int32_t B, int32_t T, const int64_t* input_id
         g.ofrag = e->t5_ffrag; g.ldo = ff; g.act = c.t5_act;
         if (c.t5_gated) { g.N = 2 * ff; g.epi = EPI_GATED_FRAG; }
         else { g.N = ff; g.epi = EPI_ACT_FRAG; }
+        if (tile) {
+            HIP_TRY(rows_norm_to_frag_launch(e->t5_x, d, w.ln1, nullptr, c.t5_eps, PRO_RMSNORM, e->stage_frag, M, d, s));
+            g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = e->stage_frag;
+        }
         PTTS_TRY(launch_gemm(e, g, s));
         g = GemmArgs();
         g.W = w.wo.ptr; g.N = d; g.K = ff; g.M = M; g.pro = PRO_FRAG; g.xfrag = e->t5_ffrag;
@@ -1281,34 +1318,38 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
         e->dec_mask = nullptr;
     }
     if (T > 0) {
+        OneOff phase(e);
+        const bool tile = tile_rows_path(e, M);
         // enc_to_dec_proj (+bias) then * attention_mask (M:2010-2017); rowmask index = b*T + t = flat mask index
         const float* enc_h = enc_states;
         GemmArgs g;
         if (c.enc_hidden != c.hidden) {
             g.W = e->enc_proj.ptr; g.N = D; g.K = c.enc_hidden; g.M = M; g.pro = PRO_ROWMAJOR; g.x = enc_states; g.ldx = c.enc_hidden;
             g.epi = EPI_ROWMAJOR; g.out = e->enc_h; g.ldo = D; g.bias = e->enc_proj_bias; g.rowmask = attention_mask;
+            if (tile) {
+                HIP_TRY(rows_norm_to_frag_launch(enc_states, c.enc_hidden, nullptr, nullptr, 0.f, PRO_ROWMAJOR, e->stage_frag, M, c.enc_hidden, s));
+                g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = e->stage_frag;
+            }
             PTTS_TRY(launch_gemm(e, g, s));
             enc_h = e->enc_h;
         } else {   // no enc_to_dec_proj (M:2010-2014 is skipped), only the mask multiply
             HIP_TRY(rowmask_mul_launch(enc_states, attention_mask, e->enc_h, M, D, s));
             enc_h = e->enc_h;
         }
-        // cross K/V of every layer into the cross pool (M:295-298)
+        // cross K/V of every layer into the cross pool (M:295-298); tile path: ONE conversion of the projected states serves all layers
+        if (tile) HIP_TRY(rows_norm_to_frag_launch(enc_h, D, nullptr, nullptr, 0.f, PRO_ROWMAJOR, e->stage_frag, M, D, s));
         for (int l = 0; l < c.layers; ++l) {
             g = GemmArgs();
             g.W = e->layers[l].ckv.ptr; g.N = 2 * D; g.K = D; g.M = M; g.pro = PRO_ROWMAJOR; g.x = enc_h; g.ldx = D;
             g.epi = EPI_KV_CROSS; g.pool = make_pool(e, true); g.layer = l; g.D = D; g.T = T;
+            if (tile) { g.pro = PRO_FRAG; g.x = nullptr; g.xfrag = e->stage_frag; }
             PTTS_TRY(launch_gemm(e, g, s));
         }
     }
     // loop state
     StepState st = {};
     st.pos = 0; st.cur_len = start_len; st.prompt_len = P; st.n_unfinished = B * c.codebooks;
-    HIP_TRY(hipMemcpyAsync(e->state, &st, sizeof(st), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // `st` lives on this stack frame
-    std::vector<int> ones(B * c.codebooks, 1);
-    HIP_TRY(hipMemcpyAsync(e->unfinished, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(reset_state_launch(e->state, st, e->unfinished, B * c.codebooks, s));      // by value, on the device: no host copy, no wait
     const int n_prefix = start_len - 1;     // decoder prefix columns (user `decoder_input_ids`, M:2150-2195) behind the prompt
     if (e->seq_prefill || e->dbg_stop >= 0) {
         // round-1 form (PTTS_PREFILL_SEQ=1; also the kernel-by-kernel debug hooks): the P prompt positions, then the prefix
@@ -1377,13 +1418,13 @@ int ptts_prefill(ptts_engine* e, int32_t B, int32_t B_eff, int32_t T, int32_t P,
                                                   B * c.codebooks, L, e->dt, s));
             e->xf_cur = wk.x_frag;
             e->host_pos = pos0 + npos - 1;
+            OneOff phase(e);
             return run_layers(e, s, false, wk, B_eff * npos, npos, pos0);
         };
         for (int p0 = 0; p0 < P; p0 += chunk) PTTS_TRY(run_chunk(p0, (P - p0 < chunk) ? P - p0 : chunk, true));
         for (int j0 = 0; j0 < n_prefix; j0 += chunk) PTTS_TRY(run_chunk(P + j0, (n_prefix - j0 < chunk) ? n_prefix - j0 : chunk, false));
         st.pos = P + n_prefix;
-        HIP_TRY(hipMemcpyAsync(e->state, &st, sizeof(st), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));   // `st` lives on this stack frame
+        HIP_TRY(reset_state_launch(e->state, st, nullptr, 0, s));
     }
     e->host_pos = P + start_len - 1;
     e->host_cur = start_len;
@@ -1855,6 +1896,8 @@ int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* 
     g.W = wp; g.N = Np; g.K = K; g.M = M; g.pro = prologue; g.x = X; g.ldx = K; g.gamma = gamma; g.beta = beta; g.eps = eps;
     g.epi = EPI_ROWMAJOR; g.out = Y; g.ldo = N; g.bias = bias; g.act = act;
     if (N % 16 != 0) { (void)hipFree(wp); return fail(PTTS_E_INVALID, "test gemm needs N %% 16 == 0"); }
+    // 7 / 8 = 5 / 4 with the launch marked as a one-off phase: M >= 128 rows in bf16 then run on the MFMA tile kernel (gemm_tile.hip)
+    if (prologue == 7 || prologue == 8) { g.tile_ok = 1; prologue = prologue == 7 ? 5 : 4; }
     void *wf = nullptr, *xf = nullptr;
     float *c1 = nullptr, *c2 = nullptr;
     if (prologue == 5) {   // plain rows through the fragment-input path (no normalisation)

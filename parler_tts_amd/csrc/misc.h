@@ -39,6 +39,8 @@ struct SelectArgs {
 hipError_t embed_codebooks_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s);
 hipError_t embed_prompt_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s);
 hipError_t advance_prompt_launch(StepState* st, hipStream_t s);
+// *st = v and (unfinished != NULL) unfinished[0 .. n_flags) = 1, on the device: the loop state of a new call without a host copy
+hipError_t reset_state_launch(StepState* st, const StepState& v, int* unfinished, int n_flags, hipStream_t s);
 // batched prefill: rows b * npos + i of x (+ fragments) for the chunk's positions pos0 .. pos0 + npos - 1.
 // prompt rows: embed_prompts[prompt_ids[b][pos]] (or the pre-embedded row) + pos_table[pos];
 // prefix rows (decoder_input_ids columns): sum_k embed_tokens[k][masked id of column col0 + i] + pos_table[pos0 + i]

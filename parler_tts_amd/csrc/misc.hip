@@ -83,6 +83,14 @@ __global__ void embed_prompt_kernel(EmbedArgs a) {
 
 __global__ void advance_prompt_kernel(StepState* s) { s->pos += 1; }
 
+// loop state of a new call, written on the device (a hipMemcpyAsync from the host's stack needed a stream synchronisation behind
+// it - three of them per prefill, each one an idle device and a cold launch queue in front of the next phase)
+__global__ void reset_state_kernel(StepState* s, StepState v, int* unfinished, int n_flags) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *s = v;
+    if (unfinished)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_flags; i += gridDim.x * blockDim.x) unfinished[i] = 1;
+}
+
 // batched prefill, prompt rows: one block per (utterance b, chunk position i)
 template <typename P>
 __global__ void embed_prompt_rows_kernel(EmbedArgs a, int npos, int pos0) {
@@ -567,6 +575,10 @@ hipError_t embed_prefix_rows_launch(const EmbedArgs& a, int B, int npos, int pos
         hipLaunchKernelGGL(embed_prefix_rows_kernel<PBF16>, dim3(B * npos), dim3(256), 0, s, a, npos, pos0, col0, raw_ids, pattern, rows_src, L);
     else
         hipLaunchKernelGGL(embed_prefix_rows_kernel<PF32>, dim3(B * npos), dim3(256), 0, s, a, npos, pos0, col0, raw_ids, pattern, rows_src, L);
+    return hipGetLastError();
+}
+hipError_t reset_state_launch(StepState* st, const StepState& v, int* unfinished, int n_flags, hipStream_t s) {
+    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(256), 0, s, st, v, unfinished, n_flags);
     return hipGetLastError();
 }
 hipError_t advance_prompt_launch(StepState* st, hipStream_t s) {

@@ -155,6 +155,46 @@ def test_fragment_gemm_partial_bursts(hip, dtype, pro, M, N, K):
     assert err <= tol, (err, tol)
 
 
+@pytest.mark.parametrize("M,N,K,pro,act", [(128, 1024, 1024, 7, 0), (1280, 2304, 768, 7, 0), (300, 9792, 1024, 7, 1), (512, 768, 2048, 7, 0),
+                                           (130, 64, 96, 7, 2), (1280, 128, 32, 7, 0), (256, 1072, 256, 7, 0), (512, 3072, 1024, 8, 0),
+                                           (200, 4096, 1024, 8, 1), (129, 1024, 1536, 8, 0), (1280, 3072, 1024, 8, 0)])
+def test_tile_gemm_against_torch(hip, M, N, K, pro, act):
+    """The 128 x 128 MFMA tile kernel of the one-off phases (csrc/gemm_tile.hip; T5 encoder M:2229, batched prefill M:794-978, cross
+    K / V M:295-298) against torch in float64 on the bf16-rounded operands: plain rows (7) and the folded LayerNorm with its
+    matrix-core row statistics (8); both tile shapes (128 x 128 with a ring of 4 stages where that fills the chip, 64 x 64 with a ring
+    of 8 elsewhere), ragged last row tile, feature-block counts that are no multiple of the tile (612 = 76.5 x 8, 67 = 16.75 x 4),
+    odd k-step counts and products shorter than the ring (K = 96, K = 32), rows with a non-zero mean."""
+    g = torch.Generator().manual_seed(M * 11 + N + K)
+    W = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    X = ((0.4 if pro == 8 else 0.0) + torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g))).cuda()
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).cuda()
+    beta = (0.1 * torch.randn(K, generator=g)).cuda()
+    bias = (torch.zeros(N) if pro == 8 else 0.1 * torch.randn(N, generator=g)).cuda()
+    Y = torch.full((M, N), 7.0, device="cuda")
+    rc = hip.ptts_test_gemm(1, M, N, K, W.data_ptr(), X.data_ptr(), pro, gamma.data_ptr(), beta.data_ptr(), C.c_float(1e-5), act,
+                            bias.data_ptr(), Y.data_ptr(), None)
+    assert rc == 0, hip.ptts_last_error()
+    Xd, Wd = X.bfloat16().double(), W.bfloat16().double()
+    if pro == 8:
+        ref = torch.nn.functional.layer_norm(Xd, (K,), gamma.double(), beta.double(), 1e-5) @ Wd.t()
+    else:
+        ref = Xd @ Wd.t() + bias.double()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    assert not torch.isnan(Y).any()
+    err = (Y.double() - ref).abs().max().item()
+    tol = (3e-3 if pro == 8 else 2e-5) * max(ref.abs().max().item(), 1.0)       # 8: gamma is folded into bf16 weights (one more rounding)
+    assert err <= tol, (err, tol)
+    # the same product on the 32-row decode kernel (prologue 5 / 4): same operands, another fp32 summation order
+    Y2 = torch.empty_like(Y)
+    rc = hip.ptts_test_gemm(1, M, N, K, W.data_ptr(), X.data_ptr(), 5 if pro == 7 else 4, gamma.data_ptr(), beta.data_ptr(),
+                            C.c_float(1e-5), act, bias.data_ptr(), Y2.data_ptr(), None)
+    assert rc == 0, hip.ptts_last_error()
+    assert (Y - Y2).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
+
+
 # ------------------------------------------------------------------------------------------------
 # decode loop vs golden fixtures of the reference
 # ------------------------------------------------------------------------------------------------
@@ -2081,6 +2121,59 @@ def test_batched_prefill_equals_position_at_a_time_prefill(hip, dtype):
         c = _fresh_engine_logits(name, dtype, {"PTTS_PREFILL_SEQ": None, "PTTS_PREFILL_CHUNK": "3"})
         assert (a - b).abs().max().item() < tol, (name, (a - b).abs().max().item())
         assert (a - c).abs().max().item() < tol, (name, (a - c).abs().max().item())
+
+
+def test_one_off_phases_on_the_tile_kernel_against_the_32_row_kernels_bf16(hip):
+    """T5 encoder, cross K / V and batched prefill at the benchmark's row counts (32 x 40 = 1280 description rows, 32 x 16 = 512
+    prompt rows; ragged masks) on the 128 x 128 MFMA tile kernel (default) against the same phases on the 32-row decode kernels
+    (PTTS_PREFILL_M128=0): same operands and rounding points, another fp32 summation order -> encoder states within fp32
+    rounding amplified by the bf16 roundings between the layers, teacher-forced logits within the bf16 bound of the restatement;
+    and the default against the bf16 restatement itself (the yardstick of every bf16 test)."""
+    from oracle import cpu_ref
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    cfg.decoder.num_hidden_layers = 2
+    cfg.text_encoder.num_layers = 3
+    sd = synthetic_state_dict(cfg, seed=7, never_eos=True, ln_jitter=0.1, parts=("text_encoder", "decoder"))
+    g = torch.Generator().manual_seed(5)
+    B, T = 32, 40
+    desc = torch.randint(2, cfg.text_encoder.vocab_size, (B, T), generator=g)
+    amask = torch.ones(B, T, dtype=torch.long)
+    for b in range(1, B):
+        amask[b, T - (7 * b) % (T // 2):] = 0
+    want = cpu_ref.t5_encode(cfg, sd, desc, amask)
+    enc = {}
+    for off in (False, True):
+        if off:
+            os.environ["PTTS_PREFILL_M128"] = "0"
+        try:
+            _models.clear()
+            torch.cuda.empty_cache()
+            model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device="cuda:0")
+            enc[off] = model.engine(B, T, 16, 16).t5_encode(desc, amask).cpu()
+            del model
+        finally:
+            os.environ.pop("PTTS_PREFILL_M128", None)
+    m = amask[..., None].float()
+    assert ((enc[False] - want).abs() * m).max() < 0.15 and ((enc[True] - want).abs() * m).max() < 0.15
+    assert ((enc[False] - enc[True]).abs() * m).max() < 0.05, ((enc[False] - enc[True]).abs() * m).max()
+    # prefill + cross K / V: teacher-forced logits of the first steps
+    sd = synthetic_state_dict(cfg, seed=7, never_eos=True, ln_jitter=0.1, parts=("decoder",))
+    for ragged in (False, True):
+        got, ref, _, _ = _oracle_vs_engine(cfg, sd, "bf16", B=32, T=40, P=16, L=10, seed=8, steps=8, oracle="bf16", ragged=ragged)
+        tol = _bf16_bound(cfg, _oracle_vs_engine.spread)
+        os.environ["PTTS_PREFILL_M128"] = "0"
+        try:
+            alt, _, _, _ = _oracle_vs_engine(cfg, sd, "bf16", B=32, T=40, P=16, L=10, seed=8, steps=8, oracle="bf16", ragged=ragged,
+                                             reuse_ref=True)
+        finally:
+            del os.environ["PTTS_PREFILL_M128"]
+        assert (got - ref).abs().max() < tol and (alt - ref).abs().max() < tol, (ragged, (got - ref).abs().max(), tol)
+        assert (got - alt).abs().max() < tol, (ragged, (got - alt).abs().max(), tol)
+        assert not torch.equal(got, alt)          # the switch does change the path (another summation order)
 
 
 def test_batched_prefill_long_prompt_and_prefix_fp32(hip):
