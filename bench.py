@@ -804,7 +804,7 @@ def main():
                 "gflop_survey_8d_closed_form": round(fl["survey_8d_closed_form"] / 1e9, 1), "ms": round(ms, 3),
                 "tflops": round(fl["total"] / 1e12 / (ms / 1e3), 1),
                 "frac_of_bf16_dense_peak_2500": round(fl["total"] / 1e12 / (ms / 1e3) / 2500.0, 4),
-                "kernel": "gemm_tile_kernel (csrc/gemm_tile.hip: 128 x 128 MFMA tiles, operands by LDS-DMA) for every product of >= 128 rows in the "
+                "kernel": "gemm_tile_kernel (csrc/gemm_tile.hip: 64 x 64 MFMA tiles, operands by LDS-DMA, ring of 4 stages) for every product of these phases in the "
                           "bf16 mode; PTTS_PREFILL_M128=0 = the 32-row decode kernels of rounds 1-5 (12.4 ms, 0.026 of the peak on the r05 record)"
                           if args.dtype == "bf16" else "gemm_kernel with M / 32 m-tiles (fp32 parity mode: 4 x v_mfma_f32_16x16x4_f32 per tile)"})(
                 t5_prefill_flops(cfg, B, T, P), phase["t5_prefill_ms"] / args.steps),

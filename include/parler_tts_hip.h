@@ -247,8 +247,11 @@ int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* byt
  * not a fallback - produced the waveform it compared.  counts_host[i], i < n:
  *   0 conv_last_kernel  1 / 2 conv1x1_stream_kernel<96 / 192>  3 / 4 fused residual unit (conv_kernel_h3r<.., true>) 96 / 192 wide
  *   5 conv_kernel_s1  6 / 7 / 8 conv_kernel_h3r<96, 64, taps 7 / 2 (transposed) / 1>  9 / 10 / 11 conv_kernel_h3r<192, 32, taps 7 / 2 / 1>
- *   12 conv_kernel_h3 (register-staged)  13 conv_kernel (fp32 MFMA).   PTTS_DAC_KERNEL_KINDS entries exist. */
-#define PTTS_DAC_KERNEL_KINDS 14
+ *   12 conv_kernel_h3 (register-staged)  13 conv_kernel (fp32 MFMA)
+ *   14 (round 6; not a kernel family) transposed-conv launches whose input arrived PACKED - Snake applied and split into fp16 hi / lo
+ *      halves once, by the epilogue of the layer in front (csrc/conv.h: alpha_out / in_packed) - instead of as fp32 rows.
+ *   PTTS_DAC_KERNEL_KINDS entries exist (a caller that asks for fewer gets the first n: 14 was the count up to round 5). */
+#define PTTS_DAC_KERNEL_KINDS 15
 int ptts_dac_kernel_counts(int64_t* counts_host, int32_t n, int32_t reset);
 
 /* HIP-event profile of the dominant kernel (self-attention decode, or - ABI v8 - the fused QKV projection + self-attention launch
@@ -269,8 +272,8 @@ int ptts_profile_read(ptts_engine* e, ptts_profile* out_host, int32_t reset);
  * (gamma folded into the weights, row statistics from the activation fragments, normalisation in the epilogue), 5 = plain
  * rows through the fragment-input path, 6 = 4 kept on the two-half workgroup where the dispatch would pick the
  * half-split grid (N <= 2048, M > 16; A/B of the two folded instances), 7 / 8 = 5 / 4 launched as the one-off phases launch
- * them: with M >= 128 rows in the bf16 mode the product runs on the 128 x 128 MFMA tile kernel (csrc/gemm_tile.hip) that the T5
- * encoder, the batched prefill and the cross K / V projections use.  With PTTS_TEST_GEMM_ITERS=n in
+ * them: in the bf16 mode the product runs on the 64 x 64 MFMA tile kernel (csrc/gemm_tile.hip) that the T5 encoder, the batched
+ * prefill and the cross K / V projections use.  With PTTS_TEST_GEMM_ITERS=n in
  * the environment the GEMM is relaunched n times and every result compared bitwise with the first (stderr report). */
 int ptts_test_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const float* W, const float* X, int32_t prologue,
                    const float* gamma, const float* beta, float eps, int32_t act, const float* bias, float* Y,

@@ -68,9 +68,9 @@ struct GemmArgs {
                                   // half-split grid: fewer, fatter workgroups so that the launch is one round of one workgroup per CU
     int rope_k = 0;               // EPI_QKV_SELF: the k segment goes, unrotated and in fp32, to out[row][D + n] (ldo >= 2 D) instead
                                   // of the cache; rope_launch (misc.h) rotates q in place and appends the rotated k
-    int tile_ok = 0;              // set by the ONE-OFF phases only (T5 encoder, batched prefill, cross K / V): with M >= 128 rows in
-                                  // the bf16 mode the launch may go to the 128 x 128 MFMA tile kernel (gemm_tile.hip: other fp32
-                                  // summation order).  Decode steps never set it: their instances are pinned bit for bit by tests
+    int tile_ok = 0;              // set by the ONE-OFF phases only (T5 encoder, batched prefill, cross K / V): in the bf16 mode the
+                                  // launch goes to the 64 x 64 MFMA tile kernel (gemm_tile.hip: other fp32 summation order), at
+                                  // every row count.  Decode steps never set it: their instances are pinned bit for bit by tests
 #ifdef PTTS_STAMPS
     StampRef stamps = {nullptr, -1};
 #endif
@@ -96,7 +96,7 @@ hipError_t lookahead_build_launch(const void* Wf, const void* Wo, void* out, int
 hipError_t compare_launch(const float* a, const float* b, size_t n, unsigned* count, unsigned* first, hipStream_t stream);
 hipError_t convert_launch(const float* src, void* dst, size_t n, int dtype, hipStream_t stream);
 
-// ---- gemm_tile.hip: 128 x 128 MFMA tile kernel for the one-off phases (bf16 mode, M >= 128, fragment input) ----
+// ---- gemm_tile.hip: 64 x 64 MFMA tile kernel for the one-off phases (bf16 mode, fragment input) ----
 bool gemm_tile_enabled();                                   // PTTS_PREFILL_M128=0 switches it off (A/B)
 bool gemm_tile_supported(const GemmArgs& a, int dtype);     // gemm_launch asks this first
 hipError_t gemm_tile_launch(const GemmArgs& a, hipStream_t stream);

@@ -283,7 +283,7 @@ hipError_t gemm_init() {
 }
 
 hipError_t gemm_launch(const GemmArgs& a, int dtype, hipStream_t stream) {
-    if (gemm_tile_supported(a, dtype)) return gemm_tile_launch(a, stream);      // one-off phases at M >= 128 (gemm_tile.hip)
+    if (gemm_tile_supported(a, dtype)) return gemm_tile_launch(a, stream);      // one-off phases in the bf16 mode (gemm_tile.hip)
     if (dtype == PTTS_BF16) return launch_typed<PBF16>(a, stream);
     return launch_typed<PF32>(a, stream);
 }

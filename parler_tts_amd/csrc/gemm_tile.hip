@@ -1,5 +1,5 @@
 // MFMA tile GEMM for the ONE-OFF phases of generate(): the T5 encoder (modeling_parler_tts.py:2229), the batched prefill (decoder
-// forward over all prompt positions, M:794-978) and the cross-attention K / V projections (M:295-298).  bf16 engine mode only.
+// forward over all prompt positions, M:794-978) and the cross-attention K / V projections (M:295-298).  bf16 engine mode only, every row count.
 //
 // Why a second GEMM kernel.  gemm_kernel (gemm.hip) is built for the decode step: a workgroup owns ONE 16-feature block of ONE
 // 32-row m-tile and its waves split K - at 32 rows the weights are read once and the launch is a latency chain.  The one-off
@@ -45,7 +45,8 @@ namespace {
 #include "gemm_device.inc"
 
 constexpr int TILE_KS = 2;                                              // k-steps (of 32) per stage
-constexpr int TILE_MIN_M = 128;                                         // fewer rows stay on gemm_kernel
+// (no row threshold: a description encoded alone must get the same bits as inside a batch of 32 - tests hold generate() to that -
+// so EVERY launch of a one-off phase takes this kernel in the bf16 mode, whatever its row count)
 // T8 = weight blocks = row tiles (of 16) per workgroup tile: 4 (64 x 64) is the instance in use (8 = 128 x 128 was measured); S = stages in the LDS ring
 template <int T8, int S> struct TileCfg {
     static constexpr int STAGE_TILES = 2 * T8 * TILE_KS;                // 1-KiB tiles per stage: T8 weight blocks + T8 row tiles, x 2 k-steps
@@ -308,7 +309,7 @@ bool gemm_tile_enabled() {      // read per call (one-off phases only, never a r
 
 bool gemm_tile_supported(const GemmArgs& a, int dtype) {
     if (dtype != PTTS_BF16 || !a.tile_ok || !gemm_tile_enabled()) return false;
-    if (a.M < TILE_MIN_M || a.pro != PRO_FRAG || !a.xfrag || a.force_whole) return false;
+    if (a.M < 1 || a.pro != PRO_FRAG || !a.xfrag || a.force_whole) return false;
     if (a.K % 32 != 0 || a.N % 16 != 0) return false;
     if (a.epi == EPI_GATED_FRAG && a.N % 32 != 0) return false;
     if (a.W2 && (a.K2 % 32 != 0 || a.N2 % 16 != 0 || !a.xfrag_lo || !a.out2 || a.ksplit <= 0 || a.ksplit >= a.K2 / 32)) return false;

@@ -156,14 +156,15 @@ def test_fragment_gemm_partial_bursts(hip, dtype, pro, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,pro,act", [(128, 1024, 1024, 7, 0), (1280, 2304, 768, 7, 0), (300, 9792, 1024, 7, 1), (512, 768, 2048, 7, 0),
-                                           (130, 64, 96, 7, 2), (1280, 128, 32, 7, 0), (256, 1072, 256, 7, 0), (512, 3072, 1024, 8, 0),
+                                           (130, 64, 96, 7, 2), (1280, 128, 32, 7, 0), (256, 1072, 256, 7, 0), (7, 256, 128, 7, 0),
+                                           (40, 3072, 1024, 8, 0), (512, 3072, 1024, 8, 0),
                                            (200, 4096, 1024, 8, 1), (129, 1024, 1536, 8, 0), (1280, 3072, 1024, 8, 0)])
 def test_tile_gemm_against_torch(hip, M, N, K, pro, act):
-    """The 128 x 128 MFMA tile kernel of the one-off phases (csrc/gemm_tile.hip; T5 encoder M:2229, batched prefill M:794-978, cross
+    """The MFMA tile kernel of the one-off phases (csrc/gemm_tile.hip; T5 encoder M:2229, batched prefill M:794-978, cross
     K / V M:295-298) against torch in float64 on the bf16-rounded operands: plain rows (7) and the folded LayerNorm with its
-    matrix-core row statistics (8); both tile shapes (128 x 128 with a ring of 4 stages where that fills the chip, 64 x 64 with a ring
-    of 8 elsewhere), ragged last row tile, feature-block counts that are no multiple of the tile (612 = 76.5 x 8, 67 = 16.75 x 4),
-    odd k-step counts and products shorter than the ring (K = 96, K = 32), rows with a non-zero mean."""
+    matrix-core row statistics (8); ragged last row tile, fewer rows than one tile (one description alone), feature-block counts
+    that are no multiple of the tile (67 = 16.75 x 4), odd k-step counts and products shorter than the ring (K = 96, K = 32), rows
+    with a non-zero mean."""
     g = torch.Generator().manual_seed(M * 11 + N + K)
     W = (torch.randn(N, K, generator=g) * 0.05).cuda()
     X = ((0.4 if pro == 8 else 0.0) + torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g))).cuda()
@@ -1185,9 +1186,9 @@ def _production_kernel_counts(frames_ge_1024):
     """launches per kernel family of ONE mini-codec decode in the default environment (conv.hip dispatch): conv0 and the
     first transposed conv have F and F + 1 GEMM rows, so below 1024 frames those two stay on the register-staged kernel"""
     want = dict(last=1, fused96=3, fused192=3, s1=6, ring192_t7=6, ring192_t2=3, h3=2, f32=0, stream96=0, stream192=0,
-                ring96_t7=0, ring96_t2=0, ring96_t1=0, ring192_t1=0)
+                ring96_t7=0, ring96_t2=0, ring96_t1=0, ring192_t1=0, packed_in=3)
     if frames_ge_1024:
-        want.update(ring192_t7=7, ring192_t2=4, h3=0)
+        want.update(ring192_t7=7, ring192_t2=4, h3=0, packed_in=4)     # every transposed conv reads packed activations (round 6)
     return want
 
 
@@ -1236,6 +1237,40 @@ def test_dac_production_kernels_against_the_oracle_at_production_sizes(hip, name
         a, b = (int(x) for x in f[f"win{i}_range"])
         dw = wav[:, a:b] - torch.from_numpy(f[f"win{i}"]).double()
         assert float(dw.pow(2).mean().sqrt()) < 1e-5 and float(dw.abs().max()) < 1e-4, (i, float(dw.abs().max()))
+
+
+def test_dac_packed_activations_equal_the_fp32_hand_over_bit_for_bit(hip):
+    """Round 6: the layer in front of every transposed conv (conv0, the last residual unit of blocks 1-3) applies that conv's
+    Snake and the fp16 hi / lo split ONCE per element in its epilogue and hands the quads over packed; the transposed conv's
+    staging pass - which used to recompute both for each of its 32 / 16 / 4 / 1 output blocks - copies them (csrc/conv.h:
+    alpha_out / in_packed).  Same Snake, same split, same MFMA operands: the waveform must be BIT-IDENTICAL to the fp32 hand-over
+    (PTTS_DAC_NO_PRESPLIT=1), at the benchmark clip length on the production kernels and at 300 frames where conv0 and the
+    first transposed conv stay on the register-staged kernel (no packing for that pair), alone and in a batch."""
+    from parler_tts_amd import _hip
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
+    g = torch.Generator().manual_seed(3)
+    for B, F, packed in ((1, 2571, 4), (3, 1100, 4), (2, 300, 3)):
+        codes = torch.randint(0, 1024, (B, 9, F), generator=g)
+        out = {}
+        for off in (False, True):
+            if off:
+                os.environ["PTTS_DAC_NO_PRESPLIT"] = "1"
+            try:
+                dac = DACModel(cfg, sd, device="cuda:0")
+                dac.decode(codes[None, :, :, :8], [None])
+                _hip.dac_kernel_counts(reset=True)
+                out[off] = dac.decode(codes[None], [None]).audio_values.cpu()
+                counts = _hip.dac_kernel_counts(reset=True)
+                assert counts["packed_in"] == (0 if off else packed), (B, F, off, counts)
+                del dac
+            finally:
+                os.environ.pop("PTTS_DAC_NO_PRESPLIT", None)
+            torch.cuda.empty_cache()
+        assert float(out[False].abs().max()) > 0.05 and torch.equal(out[False], out[True]), (B, F)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -2125,7 +2160,7 @@ def test_batched_prefill_equals_position_at_a_time_prefill(hip, dtype):
 
 def test_one_off_phases_on_the_tile_kernel_against_the_32_row_kernels_bf16(hip):
     """T5 encoder, cross K / V and batched prefill at the benchmark's row counts (32 x 40 = 1280 description rows, 32 x 16 = 512
-    prompt rows; ragged masks) on the 128 x 128 MFMA tile kernel (default) against the same phases on the 32-row decode kernels
+    prompt rows; ragged masks) on the MFMA tile kernel (default) against the same phases on the 32-row decode kernels
     (PTTS_PREFILL_M128=0): same operands and rounding points, another fp32 summation order -> encoder states within fp32
     rounding amplified by the bf16 roundings between the layers, teacher-forced logits within the bf16 bound of the restatement;
     and the default against the bf16 restatement itself (the yardstick of every bf16 test)."""
