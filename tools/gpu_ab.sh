@@ -18,7 +18,7 @@ for rep in 1 2; do
       *=*) env_kv="$v" ;;
       *) echo "bad variant $v" >&2; exit 64 ;;
     esac
-    env $env_kv python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-pass $DAC > "$O/b.json" 2> "$O/b.err"
+    env $env_kv python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-sampling-pass $DAC > "$O/b.json" 2> "$O/b.err"
     rc=$?
     if [ $rc -ne 0 ]; then echo "variant [$v] rep $rep FAILED rc=$rc" | tee -a "$O/ab.txt"; tail -n 5 "$O/b.err"; exit $rc; fi
     python3 - "$v" "$rep" "$O/b.json" <<'PY' | tee -a "$O/ab.txt"
