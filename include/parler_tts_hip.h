@@ -247,11 +247,8 @@ int ptts_debug_buffer(ptts_engine* e, const char* name, void** ptr, int64_t* byt
  * not a fallback - produced the waveform it compared.  counts_host[i], i < n:
  *   0 conv_last_kernel  1 / 2 conv1x1_stream_kernel<96 / 192>  3 / 4 fused residual unit (conv_kernel_h3r<.., true>) 96 / 192 wide
  *   5 conv_kernel_s1  6 / 7 / 8 conv_kernel_h3r<96, 64, taps 7 / 2 (transposed) / 1>  9 / 10 / 11 conv_kernel_h3r<192, 32, taps 7 / 2 / 1>
- *   12 conv_kernel_h3 (register-staged)  13 conv_kernel (fp32 MFMA)
- *   14 (round 6; not a kernel family) transposed-conv launches whose input arrived PACKED - Snake applied and split into fp16 hi / lo
- *      halves once, by the epilogue of the layer in front (csrc/conv.h: alpha_out / in_packed) - instead of as fp32 rows.
- *   PTTS_DAC_KERNEL_KINDS entries exist (a caller that asks for fewer gets the first n: 14 was the count up to round 5). */
-#define PTTS_DAC_KERNEL_KINDS 15
+ *   12 conv_kernel_h3 (register-staged)  13 conv_kernel (fp32 MFMA).   PTTS_DAC_KERNEL_KINDS entries exist. */
+#define PTTS_DAC_KERNEL_KINDS 14
 int ptts_dac_kernel_counts(int64_t* counts_host, int32_t n, int32_t reset);
 
 /* HIP-event profile of the dominant kernel (self-attention decode, or - ABI v8 - the fused QKV projection + self-attention launch

@@ -25,7 +25,7 @@ EXPORTS = [
 
 # kernel families of ptts_dac_kernel_counts (include/parler_tts_hip.h)
 DAC_KERNEL_KINDS = ["last", "stream96", "stream192", "fused96", "fused192", "s1", "ring96_t7", "ring96_t2", "ring96_t1",
-                    "ring192_t7", "ring192_t2", "ring192_t1", "h3", "f32", "packed_in"]
+                    "ring192_t7", "ring192_t2", "ring192_t1", "h3", "f32"]
 
 
 class PttsConfig(C.Structure):

@@ -185,24 +185,6 @@ __device__ inline void split_h(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
-// Round 6, "packed" activations (ConvArgs::alpha_out / in_packed, conv.h): the producer of a transposed conv's input applies that
-// conv's Snake and the fp16 hi / lo split ONCE per element in its epilogue and stores the four (hi, lo) pairs of a channel quad in
-// the quad's own 16 bytes - [h0 h1 h2 h3 | l0 l1 l2 l3] where the fp32 quad stood - so that the consumer's staging pass is two
-// 8-byte LDS writes per quad and no arithmetic.  Same Snake, same split, same values as the consumer's own stash computes from the
-// fp32 quad: the MFMA operands, and therefore the waveform, are bit-identical.
-__device__ inline float4 pack_snake_quad(float4 y, const float* __restrict__ alpha4) {
-    const float4 al = *reinterpret_cast<const float4*>(alpha4);
-    const float4 inv = make_float4(1.0f / (al.x + 1e-9f), 1.0f / (al.y + 1e-9f), 1.0f / (al.z + 1e-9f), 1.0f / (al.w + 1e-9f));
-    _Float16 h[4], l[4];
-    split_h(snake_f(y.x, al.x, inv.x), h[0], l[0]); split_h(snake_f(y.y, al.y, inv.y), h[1], l[1]);
-    split_h(snake_f(y.z, al.z, inv.z), h[2], l[2]); split_h(snake_f(y.w, al.w, inv.w), h[3], l[3]);
-    float4 out;
-    const uint2 hh = *reinterpret_cast<const uint2*>(h), ll = *reinterpret_cast<const uint2*>(l);
-    out.x = __builtin_bit_cast(float, hh.x); out.y = __builtin_bit_cast(float, hh.y);
-    out.z = __builtin_bit_cast(float, ll.x); out.w = __builtin_bit_cast(float, ll.y);
-    return out;
-}
-
 // RW = time rows per wave (32 | 64): with 64 a wave reads 8 activation + 2 NT weight fragments per tap for 12 NT MFMAs instead
 // of 4 + 2 NT for 6 NT (the MFMA loop runs the LDS pipe at ~87 % of the matrix pipe's time with RW = 32), and a staged
 // chunk feeds twice the rows
@@ -516,14 +498,6 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
             if (tid + 512 * k < nx) {
                 const int r = xrow0 + 64 * k;
                 float4 v = (xvalid >> k) & 1 ? xr[k] : make_float4(0, 0, 0, 0);
-                if constexpr (TAPS == 2) {
-                    if (a.in_packed) {     // transposed conv fed by a packing producer: the quad IS [hi x 4 | lo x 4] already (zeros stay zeros)
-                        const int xo = r * LDH + 8 * swz16(r, xq >> 1) + 4 * (xq & 1);
-                        *reinterpret_cast<uint2*>(xh + xo) = make_uint2(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y));
-                        *reinterpret_cast<uint2*>(xl + xo) = make_uint2(__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w));
-                        continue;
-                    }
-                }
 #if PTTS_CONV_ABLATE != 3       // 3 = timing-only ablation (WRONG results): the stash without Snake
                 if (snake) {   // Snake(0) = 0, so the zero padding needs no special case
                     v.x = snake_f(v.x, alr.x, inv.x); v.y = snake_f(v.y, alr.y, inv.y);
@@ -700,7 +674,6 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
                 float4 y;
                 y.x = (o[jb][0] + b2.x) + rv.x; y.y = (o[jb][1] + b2.y) + rv.y;
                 y.z = (o[jb][2] + b2.z) + rv.z; y.w = (o[jb][3] + b2.w) + rv.w;
-                if (a.alpha_out) y = pack_snake_quad(y, a.alpha_out + co);      // the next layer is a transposed conv (conv.h)
                 *reinterpret_cast<float4*>(outb2 + (size_t)u * a.Cout + co) = y;
             }
         };
@@ -805,7 +778,6 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
                 y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
             }
             if (a.act_out == 1) { y.x = tanhf(y.x); y.y = tanhf(y.y); y.z = tanhf(y.z); y.w = tanhf(y.w); }
-            if (a.alpha_out) y = pack_snake_quad(y, a.alpha_out + co);          // the next layer is a transposed conv (conv.h)
             *reinterpret_cast<float4*>(outb + (size_t)t * a.Cout + co) = y;
         }
     }
@@ -962,9 +934,6 @@ __global__ __launch_bounds__(512) void conv_kernel_s1(ConvArgs a) {
                 const float4 rv = *reinterpret_cast<const float4*>(resb + (size_t)u * a.Cout + co);
                 y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
             }
-            // the next layer is a transposed conv (conv.h): Snake + split here, once; the residual quad was read by this lane alone, so
-            // the in-place store stays safe
-            if (a.alpha_out) y = pack_snake_quad(y, a.alpha_out + co);
             *reinterpret_cast<float4*>(outb + (size_t)u * a.Cout + co) = y;
         }
     }
@@ -1355,14 +1324,6 @@ size_t conv_h3_lds(const ConvArgs& a, int TN, int RW = 32) {
 // the production kernels and not on a fallback; include/parler_tts_hip.h: ptts_dac_kernel_counts)
 static std::atomic<long long> g_conv_counts[CONV_KIND_COUNT];
 static inline void tally(int kind) { g_conv_counts[kind].fetch_add(1, std::memory_order_relaxed); }
-// conv_kind_of(): the dispatch below run as a plan - the kernel family it WOULD launch is written here and nothing is launched
-static thread_local int* g_conv_plan = nullptr;
-#define PTTS_CONV_PICK(kind) do { if (g_conv_plan) { *g_conv_plan = (kind); return hipSuccess; } } while (0)
-// packed activations (conv.h): which kernel families write them / read them
-static inline bool conv_kind_packs(int k) { return k == CONV_KIND_FUSED_96 || k == CONV_KIND_FUSED_192 || k == CONV_KIND_S1 ||
-                                                   k == CONV_KIND_RING_96_T7 || k == CONV_KIND_RING_192_T7 || k == CONV_KIND_RING_96_T1 || k == CONV_KIND_RING_192_T1; }
-static inline bool conv_kind_unpacks(int k) { return k == CONV_KIND_RING_96_T2 || k == CONV_KIND_RING_192_T2; }
-#define PTTS_CONV_PACK_GUARD(kind) do { if ((a.alpha_out && !conv_kind_packs(kind)) || (a.in_packed && !conv_kind_unpacks(kind))) return hipErrorInvalidValue; } while (0)
 void conv_kernel_counts(long long* out, int n, bool reset) {
     for (int i = 0; i < n && i < CONV_KIND_COUNT; ++i) out[i] = g_conv_counts[i].load(std::memory_order_relaxed);
     for (int i = CONV_KIND_COUNT; i < n; ++i) out[i] = 0;
@@ -1405,8 +1366,6 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     // last layer (one output channel, 7 taps): the reduction kernel
     if (getenv("PTTS_DAC_NO_LAST_KERNEL") == nullptr && a.Cout == 1 && a.N == 1 && a.taps == 7 && a.tstep == 1 && a.toff == -3 &&
         a.stride == 1 && a.Cin % 32 == 0 && a.alpha && !a.res && a.Tin == a.Tout) {
-        PTTS_CONV_PICK(CONV_KIND_LAST);
-        PTTS_CONV_PACK_GUARD(CONV_KIND_LAST);
         hipLaunchKernelGGL(conv_last_kernel, dim3((a.Tout + 255) / 256, a.B), dim3(256), 0, s, a);
         tally(CONV_KIND_LAST);
         return hipGetLastError();
@@ -1417,8 +1376,6 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
         a.N == a.Cout && a.in_bs == 0 && a.out_bs == 0 && a.Tin == a.Tout && a.U == a.Tout && (a.Cin == 96 || a.Cin == 192)) {
         const long long rows = (long long)a.B * a.Tout;
         const long long tiles = (rows + 15) / 16;
-        PTTS_CONV_PICK(a.Cin == 96 ? CONV_KIND_STREAM_96 : CONV_KIND_STREAM_192);
-        PTTS_CONV_PACK_GUARD(CONV_KIND_STREAM_96);
         if (a.Cin == 96) {
             const size_t lds = (size_t)6 * 3 * 64 * 16 * 2 + 2 * 96 * sizeof(float);
             long long g = (tiles + 3) / 4; if (g > 256 * 4) g = 256 * 4;
@@ -1456,8 +1413,6 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 if (a.taps != 7 || a.N != a.unit_tn || a.Cin != a.unit_tn || a.Cout != a.unit_tn || !a.alpha2 || !a.bias2 || a.res || a.in_bs ||
                     a.out_bs || a.out == a.in || a.stride != 1 || a.act_out)
                     return hipErrorInvalidValue;
-                PTTS_CONV_PICK(a.unit_tn == 96 ? CONV_KIND_FUSED_96 : CONV_KIND_FUSED_192);
-                PTTS_CONV_PACK_GUARD(CONV_KIND_FUSED_96);
                 if (a.unit_tn == 96) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, true>), grid, dim3(512), lds, s, a);
                 tally(a.unit_tn == 96 ? CONV_KIND_FUSED_96 : CONV_KIND_FUSED_192);
@@ -1467,18 +1422,9 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 a.U == a.Tout && a.Cin <= 2048 && getenv("PTTS_DAC_NO_S1") == nullptr) {
                 // wide 1x1 conv: activations straight into B fragments, no window
                 const size_t lds_s1 = (size_t)4 * 192 * 128 + (size_t)2 * a.Cin * sizeof(float);
-                PTTS_CONV_PICK(CONV_KIND_S1);
-                PTTS_CONV_PACK_GUARD(CONV_KIND_S1);
                 hipLaunchKernelGGL(conv_kernel_s1, grid, dim3(512), lds_s1, s, a);
                 tally(CONV_KIND_S1);
                 return hipGetLastError();
-            }
-            {
-                const int kind = (a.unit_tn == 96 ? CONV_KIND_RING_96_T7 : CONV_KIND_RING_192_T7) + (a.taps == 7 ? 0 : (a.taps == 2 ? 1 : 2));
-                PTTS_CONV_PICK(kind);
-                PTTS_CONV_PACK_GUARD(kind);
-                // a packing producer writes whole quads at (t, co): a strided (transposed) or tanh-ed output is never packed
-                if (a.alpha_out && (a.stride != 1 || a.act_out)) return hipErrorInvalidValue;
             }
             if (a.unit_tn == 96) {
                 if (a.taps == 7) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, false>), grid, dim3(512), lds, s, a);
@@ -1490,7 +1436,6 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 1, RS, false>), grid, dim3(512), lds, s, a);
             }
             tally((a.unit_tn == 96 ? CONV_KIND_RING_96_T7 : CONV_KIND_RING_192_T7) + (a.taps == 7 ? 0 : (a.taps == 2 ? 1 : 2)));
-            if (a.in_packed) tally(CONV_KIND_PACKED_IN);
             return hipGetLastError();
         }
     }
@@ -1517,8 +1462,6 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
         if (lds3 <= 160 * 1024 && span <= h3_max_span(RW)) {
             const int tmw = 8 * RW;
             dim3 grid((a.N + TN - 1) / TN, (a.U + tmw - 1) / tmw, a.B);
-            PTTS_CONV_PICK(CONV_KIND_H3);
-            PTTS_CONV_PACK_GUARD(CONV_KIND_H3);
             if (TN == 64 && RW == 32) hipLaunchKernelGGL((conv_kernel_h3<64, 32>), grid, dim3(512), lds3, s, a);
             else if (TN == 96 && RW == 32) hipLaunchKernelGGL((conv_kernel_h3<96, 32>), grid, dim3(512), lds3, s, a);
             else if (TN == 64) hipLaunchKernelGGL((conv_kernel_h3<64, 64>), grid, dim3(512), lds3, s, a);
@@ -1534,32 +1477,10 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     const size_t lds = ((size_t)win * LDA + (size_t)a.taps * TN * LDA) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((a.N + TN - 1) / TN, (a.U + TM - 1) / TM, a.B);
-    PTTS_CONV_PICK(CONV_KIND_F32);
-    PTTS_CONV_PACK_GUARD(CONV_KIND_F32);
     if (TN == 64) hipLaunchKernelGGL(conv_kernel<64>, grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL(conv_kernel<96>, grid, dim3(256), lds, s, a);
     tally(CONV_KIND_F32);
     return hipGetLastError();
-}
-
-int conv_kind_of(const ConvArgs& a) {
-    int kind = -1;
-    g_conv_plan = &kind;
-#ifdef PTTS_CONV_STAMPS
-    (void)conv_launch_inner(a, nullptr);
-#else
-    (void)conv_launch(a, nullptr);
-#endif
-    g_conv_plan = nullptr;
-    return kind;
-}
-
-bool conv_can_pack(const ConvArgs& producer, const ConvArgs& consumer) {
-    if (getenv("PTTS_DAC_NO_PRESPLIT")) return false;             // A/B and the bit-identity test
-    if (!consumer.alpha || consumer.taps != 2 || consumer.Cin != producer.Cout || producer.stride != 1 || producer.act_out ||
-        producer.out_bs || consumer.in_bs || producer.Cout % 4 != 0)
-        return false;
-    return conv_kind_packs(conv_kind_of(producer)) && conv_kind_unpacks(conv_kind_of(consumer));
 }
 
 hipError_t dac_latent_launch(const long long* codes, const float* table, float* z, int B, int K, int F, int C, int ncodes,

@@ -190,7 +190,7 @@ def test_dac_kernel_counts_hook_answers_without_a_gpu(built_lib):
     from parler_tts_amd import _hip
 
     counts = _hip.dac_kernel_counts(reset=True)
-    assert list(counts) == _hip.DAC_KERNEL_KINDS and len(counts) == 15 and set(counts.values()) == {0}
+    assert list(counts) == _hip.DAC_KERNEL_KINDS and len(counts) == 14 and set(counts.values()) == {0}
     import ctypes as C
 
     assert _hip.load_library().ptts_dac_kernel_counts(None, 0, 0) == -1

@@ -1186,9 +1186,9 @@ def _production_kernel_counts(frames_ge_1024):
     """launches per kernel family of ONE mini-codec decode in the default environment (conv.hip dispatch): conv0 and the
     first transposed conv have F and F + 1 GEMM rows, so below 1024 frames those two stay on the register-staged kernel"""
     want = dict(last=1, fused96=3, fused192=3, s1=6, ring192_t7=6, ring192_t2=3, h3=2, f32=0, stream96=0, stream192=0,
-                ring96_t7=0, ring96_t2=0, ring96_t1=0, ring192_t1=0, packed_in=3)
+                ring96_t7=0, ring96_t2=0, ring96_t1=0, ring192_t1=0)
     if frames_ge_1024:
-        want.update(ring192_t7=7, ring192_t2=4, h3=0, packed_in=4)     # every transposed conv reads packed activations (round 6)
+        want.update(ring192_t7=7, ring192_t2=4, h3=0)
     return want
 
 
@@ -1237,40 +1237,6 @@ def test_dac_production_kernels_against_the_oracle_at_production_sizes(hip, name
         a, b = (int(x) for x in f[f"win{i}_range"])
         dw = wav[:, a:b] - torch.from_numpy(f[f"win{i}"]).double()
         assert float(dw.pow(2).mean().sqrt()) < 1e-5 and float(dw.abs().max()) < 1e-4, (i, float(dw.abs().max()))
-
-
-def test_dac_packed_activations_equal_the_fp32_hand_over_bit_for_bit(hip):
-    """Round 6: the layer in front of every transposed conv (conv0, the last residual unit of blocks 1-3) applies that conv's
-    Snake and the fp16 hi / lo split ONCE per element in its epilogue and hands the quads over packed; the transposed conv's
-    staging pass - which used to recompute both for each of its 32 / 16 / 4 / 1 output blocks - copies them (csrc/conv.h:
-    alpha_out / in_packed).  Same Snake, same split, same MFMA operands: the waveform must be BIT-IDENTICAL to the fp32 hand-over
-    (PTTS_DAC_NO_PRESPLIT=1), at the benchmark clip length on the production kernels and at 300 frames where conv0 and the
-    first transposed conv stay on the register-staged kernel (no packing for that pair), alone and in a batch."""
-    from parler_tts_amd import _hip
-    from parler_tts_amd.modeling import DACModel
-    from parler_tts_amd.weights import synthetic_state_dict
-
-    cfg = config_for("dac_mini")
-    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
-    g = torch.Generator().manual_seed(3)
-    for B, F, packed in ((1, 2571, 4), (3, 1100, 4), (2, 300, 3)):
-        codes = torch.randint(0, 1024, (B, 9, F), generator=g)
-        out = {}
-        for off in (False, True):
-            if off:
-                os.environ["PTTS_DAC_NO_PRESPLIT"] = "1"
-            try:
-                dac = DACModel(cfg, sd, device="cuda:0")
-                dac.decode(codes[None, :, :, :8], [None])
-                _hip.dac_kernel_counts(reset=True)
-                out[off] = dac.decode(codes[None], [None]).audio_values.cpu()
-                counts = _hip.dac_kernel_counts(reset=True)
-                assert counts["packed_in"] == (0 if off else packed), (B, F, off, counts)
-                del dac
-            finally:
-                os.environ.pop("PTTS_DAC_NO_PRESPLIT", None)
-            torch.cuda.empty_cache()
-        assert float(out[False].abs().max()) > 0.05 and torch.equal(out[False], out[True]), (B, F)
 
 
 # ------------------------------------------------------------------------------------------------
