@@ -161,14 +161,27 @@ class HipEngine:
     def t5_encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         t5 = self.cfg.text_encoder
         B, T = input_ids.shape
-        buckets = t5_relative_buckets(T, t5.relative_attention_num_buckets, t5.relative_attention_max_distance)
-        table = self.rel_bias_weight[buckets].t().contiguous().to(self.device)      # [H][2T-1]
+        # bucketed relative-position bias [H][2T-1]: integer table on the host, gathered once per description length and kept on the
+        # device (it was rebuilt and copied host -> device at every call: a synchronous copy in front of the time to first token)
+        cache = self.__dict__.setdefault("_rel_bias_tables", {})
+        table = cache.get(T)
+        if table is None:
+            buckets = t5_relative_buckets(T, t5.relative_attention_num_buckets, t5.relative_attention_max_distance)
+            table = cache[T] = self.rel_bias_weight[buckets].t().contiguous().to(self.device)
+            if len(cache) > 64:
+                cache.pop(next(iter(cache)))
         ids = input_ids.to(self.device, torch.int64).contiguous()
         mask = attention_mask.to(self.device, torch.int32).contiguous()
         out = torch.empty(B, T, t5.d_model, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):       # streams, lazy allocations and launches follow the CURRENT device
             _hip.check(self.lib.ptts_t5_encode(self.handle, B, T, _ptr(ids), _ptr(mask), _ptr(table), _ptr(out), _stream()))
-            torch.cuda.current_stream().synchronize()  # `table`/`ids` are temporaries
+            if _stream().value:
+                # asynchronous on the caller's stream: the temporaries stay referenced until the next call has queued its own work
+                # behind this one (same stream: by then the kernels that read them are done or ordered in front)
+                self._t5_keep = (ids, mask, table)
+                ids.record_stream(torch.cuda.current_stream()); mask.record_stream(torch.cuda.current_stream())
+            else:
+                torch.cuda.current_stream().synchronize()  # NULL stream: the engine call was host-synchronous anyway
         return out
 
     def dac_decode(self, codes: torch.Tensor) -> torch.Tensor:

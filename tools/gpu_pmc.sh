@@ -5,6 +5,7 @@
 #                                          24 layers, batch 32, S = 1251 .. 1281, ~7.6k dispatches - below the profiler's AQL-ring
 #                                          wrap, profiles/r03_pmc_abort_root_cause.txt)
 #   bash tools/gpu_pmc.sh OUT dac          the four passes of the codec decode at 2 x 2571 frames (tools/dac_profile.py 2 2571)
+#   bash tools/gpu_pmc.sh OUT prefill      the same four passes over T5 encoder + prefill at the bench shape (tools/prefill_profile.py)
 # Tables: python3 tools/pmc_report.py gpurun_out/OUT.  A pass that fails or is killed ends the call with its return code.
 set -o pipefail
 P=$PWD; O=$P/gpurun_out/$1; mkdir -p "$O"
@@ -35,7 +36,15 @@ case "$2" in
     run_pmc dac_sq2 0 "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES" $DAC
     run_pmc dac_tcc 0 "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" $DAC
     run_pmc dac_grbm 0 "GRBM_GUI_ACTIVE" $DAC ;;
-  *) echo "usage: gpu_pmc.sh OUT decoder|dac" >&2; exit 64 ;;
+  prefill)
+    # T5 encoder + prefill of the benchmark shape (tools/prefill_profile.py: 4 short generate() calls, ~1.3k dispatches): the MFMA tile
+    # GEMM and the attention kernels of the one-off phases; same four passes as the codec
+    PF="python3 $P/tools/prefill_profile.py 1"
+    run_pmc dac_sq1 0 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" $PF
+    run_pmc dac_sq2 0 "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES" $PF
+    run_pmc dac_tcc 0 "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" $PF
+    run_pmc dac_grbm 0 "GRBM_GUI_ACTIVE" $PF ;;
+  *) echo "usage: gpu_pmc.sh OUT decoder|dac|prefill" >&2; exit 64 ;;
 esac
 du -sh "$O"
 exit 0

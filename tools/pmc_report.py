@@ -2,6 +2,7 @@
 """Tables from the per-kernel counter summaries tools/pmc_summary.py wrote (one JSON per rocprofv3 --pmc pass):
     python3 tools/pmc_report.py decoder DIR     -> the launches of a decode step at the bench shape
     python3 tools/pmc_report.py dac DIR         -> the codec conv kernels
+    python3 tools/pmc_report.py prefill DIR     -> T5 encoder + prefill (same table; tools/gpu_pmc.sh OUT prefill)
 Byte counts: fabric reads = 32 B x RDREQ_32B + 64 B x RDREQ_64B + 128 B x RDREQ_128B (the three size classes partition
 TCC_EA0_RDREQ on gfx950: `other` = 0 in every row), writes = 64 B x WRREQ_64B + 32 B x the rest.  The per-launch durations are
 those of the profiled run (counter collection serialises and slows the launches); shares and per-launch counts are what to read."""
@@ -55,7 +56,7 @@ else:
     print("kernel (workgroups)                                         launches  us/launch(profiled) | fabric rd GB  wr GB | wave cycles: issuing % / parked % / "
           "issue-stalled % / of which LDS % | MFMA pipe busy cycles per CU-busy cycle | MFMA:VALU instr | LDS conflict % of LDS-active | clock GHz")
     for k, r in sorted(s1.items(), key=lambda x: -x[1]["mean_ns"] * x[1]["launches"]):
-        if r["mean_ns"] * r["launches"] < 5e4:
+        if r["mean_ns"] * r["launches"] < (2e4 if mode == "prefill" else 5e4) or k not in s2 or k not in tc or k not in gr:
             continue
         a, b, c, g = (t[k]["per_launch"] for t in (s1, s2, tc, gr))
         wc = a["SQ_WAVE_CYCLES"]
