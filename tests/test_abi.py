@@ -229,3 +229,26 @@ def test_reference_side_binding_structs_match_the_header_layout(built_lib, monke
         assert [(n, getattr(mine, n).offset, getattr(mine, n).size) for n, *_ in mine._fields_] == \
                [(n, getattr(theirs, n).offset, getattr(theirs, n).size) for n, *_ in theirs._fields_]
     assert rb._lib.ptts_abi_version() == _hip.ABI_VERSION
+
+
+def test_readme_lists_every_environment_switch_the_code_reads():
+    """ONE table of the PTTS_* switches (product / A-B / test hook).  Every switch the library, the Python layer or
+    bench.py reads must be in it, and the table must not advertise switches that no longer exist."""
+    import glob
+
+    pat = re.compile(r"PTTS_[A-Z0-9_]+")
+    read = set()
+    for f in glob.glob(os.path.join(ROOT, "parler_tts_amd", "csrc", "*")):
+        if f.endswith((".hip", ".inc", ".h")):
+            read |= set(re.findall(r'getenv\("(PTTS_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(ROOT, "parler_tts_amd", "*.py")) + [os.path.join(ROOT, "bench.py")]:
+        read |= set(re.findall(r'environ(?:\.get|\.setdefault|\.pop)?[\(\[]\s*"(PTTS_[A-Z0-9_]+)"', open(f).read()))
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    a = readme.index("## Environment switches")
+    table = readme[a:]
+    listed = set(pat.findall(table))
+    internal = {"PTTS_STAMPS_OUT"}                      # diagnostic build only (tools/gpu_calls.md)
+    missing = sorted(read - listed - internal)
+    assert not missing, f"switches read by the code but absent from README's table: {missing}"
+    stale = sorted(s for s in listed - read if s not in ("PTTS_HIP_LIB",) and not s.startswith("PTTS_DAC_TILE"))
+    assert not stale, f"README lists switches nothing reads any more: {stale}"
