@@ -66,6 +66,26 @@ def gpu_pci_addresses(sysfs: str = "/") -> List[str]:
     return out
 
 
+def gpu_pci_addresses_by_bus(sysfs: str = "/") -> List[str]:
+    """Fallback when the KFD topology cannot be read (some sandboxes deny it): AMD display / accelerator functions in PCI address
+    order - the order HIP enumerates them in on the nodes this was written for, but not a guarantee, which is why the record says
+    which walk produced the binding."""
+    base = os.path.join(sysfs, "sys/bus/pci/devices")
+    out = []
+    for bdf in sorted(os.listdir(base)):
+        try:
+            with open(os.path.join(base, bdf, "vendor")) as f:
+                if f.read().strip().lower() != "0x1002":
+                    continue
+            with open(os.path.join(base, bdf, "class")) as f:
+                cls = f.read().strip().lower()
+        except OSError:
+            continue
+        if cls.startswith(("0x0300", "0x0302", "0x0380", "0x1200")):        # VGA / 3D / display / processing accelerator
+            out.append(bdf)
+    return out
+
+
 def visible_gpu_indices(n_gpus: int, env: Optional[Dict[str, str]] = None) -> List[int]:
     """physical index of every visible device, honouring ROCR_VISIBLE_DEVICES then HIP_ / CUDA_VISIBLE_DEVICES (index lists)"""
     env = os.environ if env is None else env
@@ -114,19 +134,27 @@ def bind_rank_to_numa_node(local_rank: int, local_world: int = 1, gpu_of_slot: O
         rec["why"] = "PTTS_NO_AFFINITY set"
         return rec
     sysfs = sysfs or os.environ.get("PTTS_AFFINITY_SYSFS") or "/"       # the variable: a fake tree for the CPU rehearsal test
+    stage = "KFD topology"
     try:
-        pci = gpu_pci_addresses(sysfs)
+        try:
+            pci = gpu_pci_addresses(sysfs)
+            rec["walk"] = "kfd"
+        except OSError as kfd_exc:
+            stage = f"PCI bus walk (KFD topology unreadable: {type(kfd_exc).__name__})"
+            pci = gpu_pci_addresses_by_bus(sysfs)
+            rec["walk"] = "pci-bus-order"
         vis = visible_gpu_indices(len(pci))
         slots = list(gpu_of_slot) if gpu_of_slot is not None else list(range(local_world))
         if local_rank >= len(slots) or any(s >= len(vis) for s in slots):
             rec["why"] = f"{len(vis)} visible GPU(s) in the KFD topology, rank slots {slots}"
             return rec
+        bdf = pci[vis[slots[local_rank]]]
+        rec["gpu_pci"] = bdf
+        stage = "PCI local_cpulist"
         cpus = []
         for s in slots:
             with open(os.path.join(sysfs, "sys/bus/pci/devices", pci[vis[s]], "local_cpulist")) as f:
                 cpus.append(parse_cpulist(f.read()))
-        bdf = pci[vis[slots[local_rank]]]
-        rec["gpu_pci"] = bdf
         try:
             with open(os.path.join(sysfs, "sys/bus/pci/devices", bdf, "numa_node")) as f:
                 rec["numa_node"] = int(f.read().strip())
@@ -134,12 +162,14 @@ def bind_rank_to_numa_node(local_rank: int, local_world: int = 1, gpu_of_slot: O
             pass
         allowed = sorted(os.sched_getaffinity(0))
         want = plan_affinity(local_rank, cpus, allowed)
+        rec["planned_cpus"] = format_cpulist(want)
         if not want:
             rec["why"] = f"none of the GPU's local cores ({format_cpulist(cpus[local_rank])}) is in this process's cpuset"
             return rec
+        stage = "sched_setaffinity"        # a sandbox may refuse it (EPERM on the pool's one-GPU boxes): the rank then runs unbound
         os.sched_setaffinity(0, want)
         got = sorted(os.sched_getaffinity(0))
         rec.update(bound=True, cpus=format_cpulist(got), n_cpus=len(got))
     except Exception as exc:  # noqa: BLE001 - placement is an optimisation: never the reason a rank fails to start
-        rec["why"] = f"{type(exc).__name__}: {exc}"
+        rec["why"] = f"{stage}: {type(exc).__name__}: {exc}"
     return rec

@@ -119,3 +119,30 @@ def test_eight_rank_rehearsal_carries_masks_and_the_generate_spread(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
     assert [m["bound"] for m in line["data_parallel"]["affinity_by_rank"]] == [False, False]
+
+
+def test_pci_bus_walk_when_the_kfd_topology_is_unreadable(tmp_path, monkeypatch):
+    """Some sandboxes deny the KFD topology (the pool's one-GPU boxes do, from Python): the walk falls back to AMD display /
+    accelerator functions in PCI address order and the record says so."""
+    before = sorted(os.sched_getaffinity(0))
+    if len(before) < 2:
+        pytest.skip("needs 2 cores")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "PTTS_NO_AFFINITY"):
+        monkeypatch.delenv(var, raising=False)
+    base = tmp_path / "sys/bus/pci/devices"
+    for bdf, vendor, cls, cpus in (("0000:05:00.0", "0x1002", "0x120000", A.format_cpulist(before[:1])),
+                                   ("0000:03:00.0", "0x8086", "0x020000", A.format_cpulist(before)),          # a NIC: skipped
+                                   ("0000:85:00.0", "0x1002", "0x038000", A.format_cpulist(before[1:]))):
+        d = base / bdf
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "class").write_text(cls + "\n")
+        (d / "local_cpulist").write_text(cpus + "\n")
+        (d / "numa_node").write_text("0\n")
+    assert A.gpu_pci_addresses_by_bus(str(tmp_path)) == ["0000:05:00.0", "0000:85:00.0"]
+    try:
+        rec = A.bind_rank_to_numa_node(1, 2, sysfs=str(tmp_path))
+        assert rec["walk"] == "pci-bus-order" and rec["gpu_pci"] == "0000:85:00.0" and rec["bound"] is True
+        assert sorted(os.sched_getaffinity(0)) == before[1:]
+    finally:
+        os.sched_setaffinity(0, before)
