@@ -1023,7 +1023,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->enc_h, sizeof(float) * ((size_t)Bm * cfg->max_desc_len + 32) * D);
     if (e->dt == PTTS_DTYPE_BF16) {      // rows x the widest staged input (decoder width, or the T5 width when the encoder is on board)
         const size_t srows = ((size_t)Bm * cfg->max_desc_len + 31) / 32 * 32;
-        const size_t swidth = (cfg->t5_layers > 0 && cfg->enc_hidden > D) ? cfg->enc_hidden : D;
+        const size_t swidth = cfg->enc_hidden > D ? cfg->enc_hidden : D;      // enc_to_dec_proj stages rows of the ENCODER width even without a T5 on board
         A(e->stage_frag, e->esz * srows * swidth);
     }
     A(e->tok_in, sizeof(int) * rows * K);
