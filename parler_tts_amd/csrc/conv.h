@@ -24,6 +24,15 @@ struct ConvArgs {
     int taps = 1, tstep = 1, toff = 0;
     int stride = 1, pad_t = 0;     // transposed: t = stride*u - pad_t + n / Cout
     int act_out = 0;               // 1 = tanh
+    // Packed activations between a block's last layer and the NEXT block's transposed conv (round 6; decided per pair by
+    // conv_can_pack).  A transposed conv re-stages its input window - global load, Snake, fp16 hi / lo split, ds_write, barrier - once
+    // per 192-wide output block (32 / 16 / 4 / 1 blocks) for two taps of MFMA work each time.  With `alpha_out` set the PRODUCER applies
+    // that Snake and the split once per element in its epilogue and stores, where the fp32 values of an 8-channel group stood, the
+    // 32 bytes [hi x 8 | lo x 8] (conv.hip: store_packed8); with `in_packed` set the CONSUMER is convt_dma_kernel, whose whole
+    // activation window arrives by LDS-DMA a chunk ahead - no register staging, no arithmetic, no ds_write, no stash barrier (its
+    // `alpha` is then null).  Same values as before: the waveform is bit-identical (test).
+    const float* alpha_out = nullptr;   // producer: Snake alpha [Cout] of the consuming transposed conv, or null (fp32 output)
+    int in_packed = 0;                  // consumer (2-tap ring kernels only): `in` holds packed quads
     size_t in_bs = 0, out_bs = 0;  // floats between utterances of in / out (and res); 0 = dense (Tin*Cin, Tout*Cout)
 };
 
@@ -49,6 +58,11 @@ void conv_kernel_counts(long long* out, int n, bool reset);
 
 hipError_t conv_init();
 hipError_t conv_launch(const ConvArgs& a, hipStream_t s);
+// the CONV_KIND_* conv_launch would dispatch `a` to (nothing is launched), -1 if it would refuse
+int conv_kind_of(const ConvArgs& a);
+// true when `producer` (its output = `consumer`'s input, consumer = a transposed conv with a Snake) may write packed quads and
+// `consumer` read them: both on kernel families that implement it; PTTS_DAC_NO_PRESPLIT=1 says no (A/B)
+bool conv_can_pack(const ConvArgs& producer, const ConvArgs& consumer);
 hipError_t dac_latent_launch(const long long* codes, const float* table, float* z, int B, int K, int F, int C, int ncodes,
                              hipStream_t s);
 hipError_t dac_table_launch(const float* codebook, const float* proj_w, const float* proj_b, float* table, int ncodes, int dim,

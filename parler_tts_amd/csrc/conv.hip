@@ -185,6 +185,32 @@ __device__ inline void split_h(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+// Round 6, "packed" activations (ConvArgs::alpha_out / in_packed, conv.h): the producer of a transposed conv's input applies that
+// conv's Snake and the fp16 hi / lo split ONCE per element in its epilogue and stores, where the fp32 values of an 8-channel group
+// (t, 8 k .. 8 k + 7) stood, the 32 bytes [hi x 8 | lo x 8] - each 16-byte half is then one MFMA fragment half, which is what lets the
+// consumer (convt_dma_kernel) fetch its whole activation window by LDS-DMA, with no register staging, no arithmetic and no ds_write.
+// A lane holds one channel QUAD (4 g .. 4 g + 3 of a 16-channel block): it writes its four hi values into the hi half and its four lo
+// values into the lo half of the group it shares with lane g ^ 1 (same row, same wave-instruction).  Same Snake, same split, same
+// values as the consumer's own stash computed from the fp32 quad: the MFMA operands, and therefore the waveform, are bit-identical.
+// In-place residual epilogues stay safe: the two lanes of a group overwrite each other's fp32 quad, but both belong to ONE wave
+// instruction stream - their residual loads have both completed before either store issues.
+// (al, inv) = the consumer's Snake alpha and 1 / (alpha + 1e-9) of the quad's channels: from an LDS table where the epilogue has one
+// (four IEEE divisions per quad and row were half of what the packing cost the producers), else computed here - the same fp32
+// division either way
+__device__ inline void store_packed8(float* __restrict__ row, int co, float4 y, float4 al, float4 inv) {
+    _Float16 h[4], l[4];
+    split_h(snake_f(y.x, al.x, inv.x), h[0], l[0]); split_h(snake_f(y.y, al.y, inv.y), h[1], l[1]);
+    split_h(snake_f(y.z, al.z, inv.z), h[2], l[2]); split_h(snake_f(y.w, al.w, inv.w), h[3], l[3]);
+    char* grp = reinterpret_cast<char*>(row + (co & ~7));           // 32 bytes of the 8-channel group
+    const int half = (co >> 2) & 1;                                  // this quad: channels 0-3 or 4-7 of the group
+    *reinterpret_cast<uint2*>(grp + 8 * half) = *reinterpret_cast<const uint2*>(h);
+    *reinterpret_cast<uint2*>(grp + 16 + 8 * half) = *reinterpret_cast<const uint2*>(l);
+}
+__device__ inline void store_packed8(float* __restrict__ row, int co, float4 y, const float* __restrict__ alpha4) {
+    const float4 al = *reinterpret_cast<const float4*>(alpha4);
+    store_packed8(row, co, y, al, make_float4(1.0f / (al.x + 1e-9f), 1.0f / (al.y + 1e-9f), 1.0f / (al.z + 1e-9f), 1.0f / (al.w + 1e-9f)));
+}
+
 // RW = time rows per wave (32 | 64): with 64 a wave reads 8 activation + 2 NT weight fragments per tap for 12 NT MFMAs instead
 // of 4 + 2 NT for 6 NT (the MFMA loop runs the LDS pipe at ~87 % of the matrix pipe's time with RW = 32), and a staged
 // chunk feeds twice the rows
@@ -641,7 +667,12 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
         lds_barrier();                                    // everyone is out of the last chunk: the window is dead
         float* als = reinterpret_cast<float*>(xh);        // [TN] alpha, [TN] 1 / (alpha + 1e-9)
         float* ivs = als + TN;
-        for (int i = tid; i < TN; i += 512) { const float al = a.alpha2[i]; als[i] = al; ivs[i] = 1.0f / (al + 1e-9f); }
+        float* als_o = ivs + TN;                          // [TN] / [TN]: the same pair for the CONSUMER's Snake when the output goes out packed
+        float* ivs_o = als_o + TN;
+        for (int i = tid; i < TN; i += 512) {
+            const float al = a.alpha2[i]; als[i] = al; ivs[i] = 1.0f / (al + 1e-9f);
+            if (a.alpha_out) { const float ao = a.alpha_out[i]; als_o[i] = ao; ivs_o[i] = 1.0f / (ao + 1e-9f); }
+        }
         const int g = lane >> 4;
         const size_t obs2 = (size_t)a.Tout * a.Cout;
         float* outb2 = a.out + (size_t)b * obs2;
@@ -674,7 +705,9 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
                 float4 y;
                 y.x = (o[jb][0] + b2.x) + rv.x; y.y = (o[jb][1] + b2.y) + rv.y;
                 y.z = (o[jb][2] + b2.z) + rv.z; y.w = (o[jb][3] + b2.w) + rv.w;
-                *reinterpret_cast<float4*>(outb2 + (size_t)u * a.Cout + co) = y;
+                if (a.alpha_out)      // the next layer is a transposed conv (conv.h)
+                    store_packed8(outb2 + (size_t)u * a.Cout, co, y, *reinterpret_cast<const float4*>(als_o + co), *reinterpret_cast<const float4*>(ivs_o + co));
+                else *reinterpret_cast<float4*>(outb2 + (size_t)u * a.Cout + co) = y;
             }
         };
         if constexpr (KS <= D) {
@@ -778,7 +811,179 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
                 y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
             }
             if (a.act_out == 1) { y.x = tanhf(y.x); y.y = tanhf(y.y); y.z = tanhf(y.z); y.w = tanhf(y.w); }
-            *reinterpret_cast<float4*>(outb + (size_t)t * a.Cout + co) = y;
+            if (a.alpha_out) store_packed8(outb + (size_t)t * a.Cout, co, y, a.alpha_out + co);          // the next layer is a transposed conv (conv.h)
+            else *reinterpret_cast<float4*>(outb + (size_t)t * a.Cout + co) = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// convt_dma_kernel (round 6): the transposed convs (two taps: rows u and u - 1) on PACKED input (conv.h: alpha_out / in_packed).
+//
+// conv_kernel_h3r's two-tap instance spends a 32-channel chunk as ~4.6 k cycles of matrix-pipe work and ~5.7 k of staging: global
+// loads into registers, Snake, fp16 split, ds_write, a barrier on each side - once per 192-wide output block (32 / 16 / 4 / 1 of them
+// per layer), for two taps of MFMAs each time.  Removing the arithmetic alone bought 8 % (profiles/r06_dac_packed_handover.txt): the
+// cost is the load -> ds_write -> barrier round trip.  Here the producer has already stored Snake(x) split into fp16 halves as
+// [hi x 8 | lo x 8] per 8-channel group, i.e. every 16 bytes of the input ARE one fragment half, so the activation window travels
+// exactly like the weights: `global_load_lds_dwordx4` straight into the swizzled LDS image (the per-lane SOURCE address carries the
+// swizzle and the row clamp; rows outside the utterance read a zero line), one chunk ahead, into the other of two window buffers.
+// No staging registers, no VALU, no ds_write, no stash barrier: per tap one counted wait, one barrier (the weight ring's), the DMAs of
+// the units / window to come, fragments + MFMAs - the same products in the same order as the ring kernel (bit-identical, test).
+// LDS: weight ring 3 x 24 KB + 2 windows x (hi + lo) x 272 rows x 64 B = 72 + 69.6 = 141.6 KB.
+// vmcnt (everything is LDS-DMA, in issue order; per wave: U = 3 pieces of a weight unit, W = 5 pieces of a window):
+//   prologue U[0] W[0] U[1];  step (c, tap 0): wait for U[2c], W[c] -> younger: U[2c+1] = 3;  then issue U[2c+2], W[c+1];
+//   step (c, tap 1): wait for U[2c+1] -> younger: U[2c+2], W[c+1] = 8;  then issue U[2c+3].   Past the end every index is clamped
+//   (a re-copy into a buffer nobody reads any more), so the counts are constants.
+// ------------------------------------------------------------------------------------------------
+__device__ const uint4 g_convt_zero_line[4] = {};      // what a window row outside [0, Tin) reads
+
+__global__ __launch_bounds__(512) void convt_dma_kernel(ConvArgs a) {
+    constexpr int TN = 192, NT = TN / 16, NI = 2, RW = 32, TMW = 8 * RW, RS = 3, UB = TN * 128, GU = UB / 8192;      // ring of 3: two units ahead
+    constexpr int WROWS = 272, WPIECES = 2 * (WROWS / 16), GW = (WPIECES + 7) / 8;      // window: 17 x 1 KB per plane, 34 pieces, 5 per wave
+    constexpr int WBYTES = 2 * WROWS * 64;                                             // one window buffer: hi plane, lo plane
+    static_assert(GU == 3 && GW == 5, "the vmcnt constants below");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                    // [RS][hi: TN x 64 B | lo: TN x 64 B]
+    char* win = smem + RS * UB;                           // [2][hi: WROWS x 64 B | lo: WROWS x 64 B]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * TN;
+    const int u0 = blockIdx.y * TMW;
+    const int b = blockIdx.z;
+    const int nchunks = a.Cin / KC3, nunits = nchunks * 2;
+    const char* units = reinterpret_cast<const char*>(a.w_units) + (size_t)blockIdx.x * nunits * UB;
+    const char* inb = reinterpret_cast<const char*>(a.in + (size_t)b * a.Tin * a.Cin);
+
+    auto dma_unit = [&](int u) {                          // unit u = (chunk u / 2, tap u % 2) into slot u % RS
+        const int uc = u < nunits ? u : nunits - 1;
+        const char* src = units + (size_t)uc * UB + (size_t)tid * 16;
+        char* dst = ring + (u % RS) * UB + w * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+        for (int j = 0; j < GU; ++j)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src + j * 8192), (lds_void*)(dst + j * 8192), 16, 0, 0);
+#else
+        (void)src; (void)dst;
+#endif
+    };
+    // window of chunk c: rows t = u0 - 1 + r, r = 0 .. 256 (tap 1 reads row u - 1), 32 channels = four 8-channel groups per row.
+    // Piece m (16 rows x 64 B of one plane) -> lane l: row 16 (m mod 17) + l / 4, LDS column slot l % 4 = swz16(row, group).
+    auto dma_window_piece = [&](int c, int j) {            // piece w + 8 j of window c (j < GW)
+        const int cc = c < nchunks ? c : nchunks - 1;
+        char* dstb = win + (c & 1) * WBYTES;
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void lds_void;
+        int m = w + 8 * j;
+        m = m < WPIECES ? m : WPIECES - 1;                // waves past the last piece copy it again (same bytes, same place)
+        const int plane = m >= WROWS / 16 ? 1 : 0, mp = m - plane * (WROWS / 16);
+        const int r = 16 * mp + (lane >> 2);
+        const int grp = swz16(r, lane & 3);               // the XOR is its own inverse: slot -> channel group
+        const int t = u0 - 1 + r;
+        const char* src = (r <= TMW && t >= 0 && t < a.Tin)
+                              ? inb + ((size_t)t * a.Cin + (size_t)cc * KC3 + 8 * grp) * 4 + 16 * plane
+                              : reinterpret_cast<const char*>(g_convt_zero_line);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src), (lds_void*)(dstb + plane * (WROWS * 64) + mp * 1024), 16, 0, 0);
+#else
+        (void)cc; (void)dstb; (void)inb; (void)g_convt_zero_line; (void)j;
+#endif
+    };
+    auto dma_window = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < GW; ++j) dma_window_piece(c, j);
+    };
+
+    f32x4 acc[NI][NT];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = {0, 0, 0, 0};
+
+    // Fragment reads as inline asm with hand-counted waits.  hipcc waits `lgkmcnt(0)` in front of an MFMA whose operand came from LDS
+    // however many younger reads are in flight (round 4 saw the same in conv_kernel_h3r: "still waits lgkmcnt(0) every second
+    // pair"), so a compiler-visible prefetch never gets more than a few MFMAs ahead.  LDS reads return in order: with the weight
+    // fragments read TWO output blocks ahead (three register pairs), block j's MFMAs wait until at most the four younger reads are
+    // outstanding.  The wait statement takes the registers it validates as "+v" operands, so no consumer can be scheduled above it.
+    // `spread` (tap 0): the five window pieces of chunk c + 1 go out one per two output blocks INSIDE the MFMA loop instead of in one
+    // burst behind the barrier - eight waves x eight LDS-DMA instructions in a row hold every wave's first MFMA back behind the
+    // texture addresser's queue
+    auto multiply = [&](int c, auto tc, int slot) {
+        constexpr int t = decltype(tc)::value;
+        typedef __attribute__((address_space(3))) const char lds_cchar;
+        const int xrow = w * RW + (1 - t) + (lane & 15);                          // tap 0: row u (window row u - u0 + 1), tap 1: row u - 1
+        const unsigned xbase = (unsigned)(uintptr_t)(lds_cchar*)(win + (c & 1) * WBYTES) +
+                               (unsigned)(xrow * LDH + 8 * swz16(xrow, lane >> 4)) * 2u;       // row + 16 has the same bit 2
+        const unsigned wbase = (unsigned)(uintptr_t)(lds_cchar*)(ring + slot * UB) +
+                               (unsigned)((lane & 15) * LDH + 8 * swz16(lane & 15, lane >> 4)) * 2u;
+        constexpr int XL = WROWS * 64, WL = TN * LDH * 2;                        // byte distance hi plane -> lo plane
+        half8 xfh[NI], xfl[NI], bh[3], bl[3];
+        static_assert(NI == 2, "two interleaved accumulator chains");
+#define PTTS_LDS_READ(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+        PTTS_LDS_READ(xfh[0], xbase, 0);
+        PTTS_LDS_READ(xfl[0], xbase, XL);
+        PTTS_LDS_READ(xfh[1], xbase, 1024);
+        PTTS_LDS_READ(xfl[1], xbase, XL + 1024);
+        PTTS_LDS_READ(bh[0], wbase, 0);
+        PTTS_LDS_READ(bl[0], wbase, WL);
+        PTTS_LDS_READ(bh[1], wbase, 1024);
+        PTTS_LDS_READ(bl[1], wbase, WL + 1024);
+        static_for<0, NT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 2 < NT) {
+                PTTS_LDS_READ(bh[(j + 2) % 3], wbase, (j + 2) * 1024);
+                PTTS_LDS_READ(bl[(j + 2) % 3], wbase, WL + (j + 2) * 1024);
+            }
+            if constexpr (t == 0 && (j & 1) == 1 && j / 2 < GW) dma_window_piece(c + 1, j / 2);
+            constexpr int younger = 2 * ((NT - 1 - j) < 2 ? (NT - 1 - j) : 2);        // reads issued behind block j's pair
+            if constexpr (j == 0)
+                asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(xfh[0]), "+v"(xfl[0]), "+v"(xfh[1]), "+v"(xfl[1]), "+v"(bh[0]), "+v"(bl[0]) : "n"(younger));
+            else
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j % 3]), "+v"(bl[j % 3]) : "n"(younger));
+            // product order per accumulator: lo.hi, hi.lo, hi.hi (as conv_kernel_h3 / h3r); the two row tiles' chains interleaved
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j % 3], xfh[0], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j % 3], xfh[1], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j % 3], xfl[0], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j % 3], xfl[1], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j % 3], xfh[0], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j % 3], xfh[1], acc[1][j], 0, 0, 0);
+        });
+#undef PTTS_LDS_READ
+    };
+
+    dma_unit(0);
+    dma_window(0);
+    dma_unit(1);
+    int slot = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        wait_vmcnt<GU>();                                 // own pieces of unit 2c and of window c landed (unit 2c + 1 may still fly)
+        lds_barrier();                                    // everyone's; and every wave has left unit 2c - 1 and window c - 1
+        dma_unit(2 * c + 2);
+        asm volatile("" ::: "memory");
+        multiply(c, std::integral_constant<int, 0>{}, slot);        // issues window c + 1 on the way
+        if (++slot == RS) slot = 0;
+        wait_vmcnt<GU + GW>();                            // own pieces of unit 2c + 1 landed
+        lds_barrier();
+        dma_unit(2 * c + 3);
+        asm volatile("" ::: "memory");
+        multiply(c, std::integral_constant<int, 1>{}, slot);
+        if (++slot == RS) slot = 0;
+    }
+    wait_vmcnt<0>();                                      // the clamped tail copies: nothing may be in flight when the wave ends
+
+    // ---- epilogue: conv_kernel_h3r's, transposed branch (t = stride u - pad + n / Cout) ----
+    const size_t obs = (size_t)a.Tout * a.Cout;
+    float* outb = a.out + (size_t)b * obs;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int u = u0 + w * RW + i * 16 + (lane & 15);
+        if (u >= a.U) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + 4 * (lane >> 4);
+            const int r = n / a.Cout, co = n - r * a.Cout, t = a.stride * u - a.pad_t + r;
+            if (t < 0 || t >= a.Tout) continue;
+            const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
+            *reinterpret_cast<float4*>(outb + (size_t)t * a.Cout + co) =
+                make_float4(acc[i][j][0] + bs.x, acc[i][j][1] + bs.y, acc[i][j][2] + bs.z, acc[i][j][3] + bs.w);
         }
     }
 }
@@ -921,6 +1126,11 @@ __global__ __launch_bounds__(512) void conv_kernel_s1(ConvArgs a) {
     const size_t obs = (size_t)a.Tout * a.Cout;
     float* outb = a.out + (size_t)b * obs;
     const float* resb = a.res ? a.res + (size_t)b * obs : nullptr;
+    if (a.alpha_out) {      // packed output: the consumer's (alpha, 1 / (alpha + 1e-9)) of this block's channels over the dead input tables (Cin >= TN)
+        lds_barrier();                                    // every wave is done with the input tables
+        for (int i = tid; i < TN; i += 512) { const float ao = a.alpha_out[n0 + i]; als[i] = ao; ivs[i] = 1.0f / (ao + 1e-9f); }
+        lds_barrier();
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int u = u0 + w * RW + i * 16 + t16;
@@ -934,7 +1144,10 @@ __global__ __launch_bounds__(512) void conv_kernel_s1(ConvArgs a) {
                 const float4 rv = *reinterpret_cast<const float4*>(resb + (size_t)u * a.Cout + co);
                 y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
             }
-            *reinterpret_cast<float4*>(outb + (size_t)u * a.Cout + co) = y;
+            // the next layer is a transposed conv (conv.h): Snake + split here, once (in place: see store_packed8)
+            if (a.alpha_out)
+                store_packed8(outb + (size_t)u * a.Cout, co, y, *reinterpret_cast<const float4*>(als + co - n0), *reinterpret_cast<const float4*>(ivs + co - n0));
+            else *reinterpret_cast<float4*>(outb + (size_t)u * a.Cout + co) = y;
         }
     }
 }
@@ -1296,6 +1509,8 @@ hipError_t conv_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_s1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(convt_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1324,6 +1539,14 @@ size_t conv_h3_lds(const ConvArgs& a, int TN, int RW = 32) {
 // the production kernels and not on a fallback; include/parler_tts_hip.h: ptts_dac_kernel_counts)
 static std::atomic<long long> g_conv_counts[CONV_KIND_COUNT];
 static inline void tally(int kind) { g_conv_counts[kind].fetch_add(1, std::memory_order_relaxed); }
+// conv_kind_of(): the dispatch below run as a plan - the kernel family it WOULD launch is written here and nothing is launched
+static thread_local int* g_conv_plan = nullptr;
+#define PTTS_CONV_PICK(kind) do { if (g_conv_plan) { *g_conv_plan = (kind); return hipSuccess; } } while (0)
+// packed activations (conv.h): which kernel families write them / read them
+static inline bool conv_kind_packs(int k) { return k == CONV_KIND_FUSED_96 || k == CONV_KIND_FUSED_192 || k == CONV_KIND_S1 ||
+                                                   k == CONV_KIND_RING_96_T7 || k == CONV_KIND_RING_192_T7 || k == CONV_KIND_RING_96_T1 || k == CONV_KIND_RING_192_T1; }
+static inline bool conv_kind_unpacks(int k) { return k == CONV_KIND_RING_192_T2; }      // convt_dma_kernel takes over from the 192-wide two-tap ring instance
+#define PTTS_CONV_PACK_GUARD(kind) do { if ((a.alpha_out && !conv_kind_packs(kind)) || (a.in_packed && !conv_kind_unpacks(kind))) return hipErrorInvalidValue; } while (0)
 void conv_kernel_counts(long long* out, int n, bool reset) {
     for (int i = 0; i < n && i < CONV_KIND_COUNT; ++i) out[i] = g_conv_counts[i].load(std::memory_order_relaxed);
     for (int i = CONV_KIND_COUNT; i < n; ++i) out[i] = 0;
@@ -1366,6 +1589,8 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     // last layer (one output channel, 7 taps): the reduction kernel
     if (getenv("PTTS_DAC_NO_LAST_KERNEL") == nullptr && a.Cout == 1 && a.N == 1 && a.taps == 7 && a.tstep == 1 && a.toff == -3 &&
         a.stride == 1 && a.Cin % 32 == 0 && a.alpha && !a.res && a.Tin == a.Tout) {
+        PTTS_CONV_PICK(CONV_KIND_LAST);
+        PTTS_CONV_PACK_GUARD(CONV_KIND_LAST);
         hipLaunchKernelGGL(conv_last_kernel, dim3((a.Tout + 255) / 256, a.B), dim3(256), 0, s, a);
         tally(CONV_KIND_LAST);
         return hipGetLastError();
@@ -1376,6 +1601,8 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
         a.N == a.Cout && a.in_bs == 0 && a.out_bs == 0 && a.Tin == a.Tout && a.U == a.Tout && (a.Cin == 96 || a.Cin == 192)) {
         const long long rows = (long long)a.B * a.Tout;
         const long long tiles = (rows + 15) / 16;
+        PTTS_CONV_PICK(a.Cin == 96 ? CONV_KIND_STREAM_96 : CONV_KIND_STREAM_192);
+        PTTS_CONV_PACK_GUARD(CONV_KIND_STREAM_96);
         if (a.Cin == 96) {
             const size_t lds = (size_t)6 * 3 * 64 * 16 * 2 + 2 * 96 * sizeof(float);
             long long g = (tiles + 3) / 4; if (g > 256 * 4) g = 256 * 4;
@@ -1413,6 +1640,8 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 if (a.taps != 7 || a.N != a.unit_tn || a.Cin != a.unit_tn || a.Cout != a.unit_tn || !a.alpha2 || !a.bias2 || a.res || a.in_bs ||
                     a.out_bs || a.out == a.in || a.stride != 1 || a.act_out)
                     return hipErrorInvalidValue;
+                PTTS_CONV_PICK(a.unit_tn == 96 ? CONV_KIND_FUSED_96 : CONV_KIND_FUSED_192);
+                PTTS_CONV_PACK_GUARD(CONV_KIND_FUSED_96);
                 if (a.unit_tn == 96) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, true>), grid, dim3(512), lds, s, a);
                 tally(a.unit_tn == 96 ? CONV_KIND_FUSED_96 : CONV_KIND_FUSED_192);
@@ -1422,9 +1651,28 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 a.U == a.Tout && a.Cin <= 2048 && getenv("PTTS_DAC_NO_S1") == nullptr) {
                 // wide 1x1 conv: activations straight into B fragments, no window
                 const size_t lds_s1 = (size_t)4 * 192 * 128 + (size_t)2 * a.Cin * sizeof(float);
+                PTTS_CONV_PICK(CONV_KIND_S1);
+                PTTS_CONV_PACK_GUARD(CONV_KIND_S1);
                 hipLaunchKernelGGL(conv_kernel_s1, grid, dim3(512), lds_s1, s, a);
                 tally(CONV_KIND_S1);
                 return hipGetLastError();
+            }
+            if (a.in_packed) {    // transposed conv on packed input: the LDS-DMA window kernel (conv_can_pack has checked the pair)
+                if (a.unit_tn != 192 || a.taps != 2 || a.tstep != -1 || a.toff != 0 || a.stride < 2 || a.in_bs || a.out_bs || a.res || a.act_out ||
+                    a.alpha || a.alpha_out || a.U != a.Tin + 1 || a.Cin % 8 != 0)
+                    return hipErrorInvalidValue;
+                PTTS_CONV_PICK(CONV_KIND_RING_192_T2);
+                const size_t lds_t = (size_t)3 * 192 * 128 + (size_t)2 * 2 * 272 * 64;
+                hipLaunchKernelGGL(convt_dma_kernel, grid, dim3(512), lds_t, s, a);
+                tally(CONV_KIND_RING_192_T2);
+                return hipGetLastError();
+            }
+            {
+                const int kind = (a.unit_tn == 96 ? CONV_KIND_RING_96_T7 : CONV_KIND_RING_192_T7) + (a.taps == 7 ? 0 : (a.taps == 2 ? 1 : 2));
+                PTTS_CONV_PICK(kind);
+                PTTS_CONV_PACK_GUARD(kind);
+                // a packing producer writes whole quads at (t, co): a strided (transposed) or tanh-ed output is never packed
+                if (a.alpha_out && (a.stride != 1 || a.act_out)) return hipErrorInvalidValue;
             }
             if (a.unit_tn == 96) {
                 if (a.taps == 7) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, false>), grid, dim3(512), lds, s, a);
@@ -1462,6 +1710,8 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
         if (lds3 <= 160 * 1024 && span <= h3_max_span(RW)) {
             const int tmw = 8 * RW;
             dim3 grid((a.N + TN - 1) / TN, (a.U + tmw - 1) / tmw, a.B);
+            PTTS_CONV_PICK(CONV_KIND_H3);
+            PTTS_CONV_PACK_GUARD(CONV_KIND_H3);
             if (TN == 64 && RW == 32) hipLaunchKernelGGL((conv_kernel_h3<64, 32>), grid, dim3(512), lds3, s, a);
             else if (TN == 96 && RW == 32) hipLaunchKernelGGL((conv_kernel_h3<96, 32>), grid, dim3(512), lds3, s, a);
             else if (TN == 64) hipLaunchKernelGGL((conv_kernel_h3<64, 64>), grid, dim3(512), lds3, s, a);
@@ -1477,10 +1727,33 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     const size_t lds = ((size_t)win * LDA + (size_t)a.taps * TN * LDA) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((a.N + TN - 1) / TN, (a.U + TM - 1) / TM, a.B);
+    PTTS_CONV_PICK(CONV_KIND_F32);
+    PTTS_CONV_PACK_GUARD(CONV_KIND_F32);
     if (TN == 64) hipLaunchKernelGGL(conv_kernel<64>, grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL(conv_kernel<96>, grid, dim3(256), lds, s, a);
     tally(CONV_KIND_F32);
     return hipGetLastError();
+}
+
+int conv_kind_of(const ConvArgs& a) {
+    int kind = -1;
+    g_conv_plan = &kind;
+#ifdef PTTS_CONV_STAMPS
+    (void)conv_launch_inner(a, nullptr);
+#else
+    (void)conv_launch(a, nullptr);
+#endif
+    g_conv_plan = nullptr;
+    return kind;
+}
+
+bool conv_can_pack(const ConvArgs& producer, const ConvArgs& consumer) {
+    if (getenv("PTTS_DAC_NO_PRESPLIT")) return false;             // A/B and the bit-identity test
+    if (!consumer.alpha || consumer.taps != 2 || consumer.Cin != producer.Cout || producer.stride != 1 || producer.act_out ||
+        producer.out_bs || consumer.in_bs || consumer.out_bs || producer.Cout % 8 != 0 || consumer.unit_tn != 192 || consumer.tstep != -1 ||
+        consumer.toff != 0 || consumer.stride < 2 || consumer.res || consumer.act_out || consumer.U != consumer.Tin + 1)
+        return false;
+    return conv_kind_packs(conv_kind_of(producer)) && conv_kind_unpacks(conv_kind_of(consumer));
 }
 
 hipError_t dac_latent_launch(const long long* codes, const float* table, float* z, int B, int K, int F, int C, int ncodes,

@@ -1694,36 +1694,51 @@ int ptts_dac_decode(ptts_engine* e, int32_t B, int32_t F, const int64_t* codes, 
         HIP_TRY(dac_latent_launch((const long long*)codes + (size_t)b0 * c.codebooks * F, e->dac_table, cur, nb, c.codebooks, F,
                                   c.dac_latent, c.dac_codebook_size, s));
         int T = F;
-        for (size_t i = 0; i < e->dac.size(); ++i) {
+        // arguments of layer i at T input frames (pointers: `cur` in, `nxt` out)
+        auto layer_args = [&](size_t i, int T_, float* cur_, float* nxt_) {
             const ConvLayer& L = e->dac[i];
             const bool last = i + 1 == e->dac.size();
             ConvArgs a;
-            a.in = cur; a.w = L.w; a.w_hi = L.w_hi; a.w_lo = L.w_lo; a.bias = L.bias; a.alpha = L.needs_alpha ? L.alpha : nullptr;
+            a.in = cur_; a.w = L.w; a.w_hi = L.w_hi; a.w_lo = L.w_lo; a.bias = L.bias; a.alpha = L.needs_alpha ? L.alpha : nullptr;
             a.w_units = L.w_units; a.unit_tn = L.unit_tn;
-            a.B = nb; a.Tin = T; a.Cin = L.Cin; a.Cout = L.Cout;
+            a.B = nb; a.Tin = T_; a.Cin = L.Cin; a.Cout = L.Cout;
             if (L.transposed) {
-                a.Tout = T * L.stride; a.N = L.stride * L.Cout; a.U = T + 1; a.taps = 2; a.tstep = -1; a.toff = 0;
-                a.stride = L.stride; a.pad_t = L.stride / 2; a.out = nxt;
+                a.Tout = T_ * L.stride; a.N = L.stride * L.Cout; a.U = T_ + 1; a.taps = 2; a.tstep = -1; a.toff = 0;
+                a.stride = L.stride; a.pad_t = L.stride / 2; a.out = nxt_;
             } else {
-                a.Tout = T; a.N = L.Cout; a.U = T; a.taps = L.k; a.tstep = L.dil; a.toff = -((L.k - 1) * L.dil) / 2;
+                a.Tout = T_; a.N = L.Cout; a.U = T_; a.taps = L.k; a.tstep = L.dil; a.toff = -((L.k - 1) * L.dil) / 2;
                 // residual unit: conv7 writes h to the other buffer, conv1 adds into the unit's input in place
                 const bool is_res_conv1 = (L.k == 1);
-                if (is_res_conv1) { a.out = nxt; a.res = nxt; }
-                else a.out = last ? out + (size_t)b0 * F * hop : nxt;
+                if (is_res_conv1) { a.out = nxt_; a.res = nxt_; }
+                else a.out = last ? out + (size_t)b0 * F * hop : nxt_;
                 if (last) a.act_out = 1;
             }
+            return a;
+        };
+        bool packed = false;           // the current activation holds packed (Snake'd, hi / lo split) quads: conv.h, alpha_out / in_packed
+        for (size_t i = 0; i < e->dac.size(); ++i) {
+            const ConvLayer& L = e->dac[i];
+            const bool last = i + 1 == e->dac.size();
+            ConvArgs a = layer_args(i, T, cur, nxt);
+            if (packed) { a.alpha = nullptr; a.in_packed = 1; packed = false; }     // set by the producer below: this IS the transposed conv
             // residual unit whose channels fit one output block: conv7 -> snake -> conv1 -> + x in one launch (conv.h, w2_units)
-            if (fuse_units && !L.transposed && L.k == 7 && !last && L.unit_tn == L.Cin && L.Cin == L.Cout && 6 * L.dil <= 64 &&
-                e->dac[i + 1].k == 1 && e->dac[i + 1].w2_units && e->dac[i + 1].Cin == L.Cout) {
+            const bool fused = fuse_units && !L.transposed && L.k == 7 && !last && L.unit_tn == L.Cin && L.Cin == L.Cout && 6 * L.dil <= 64 &&
+                               e->dac[i + 1].k == 1 && e->dac[i + 1].w2_units && e->dac[i + 1].Cin == L.Cout;
+            if (fused) {
                 const ConvLayer& L1 = e->dac[i + 1];
                 a.out = nxt; a.res = nullptr;
                 a.w2_units = L1.w2_units; a.bias2 = L1.bias; a.alpha2 = L1.alpha;
-                HIP_TRY(conv_launch(a, s));
-                std::swap(cur, nxt);
-                ++i;
-                continue;
+            }
+            // the layer whose output feeds a transposed conv (conv0, or the last residual unit of a block) hands it over packed where
+            // both kernels can (conv_can_pack)
+            const size_t q = i + (fused ? 2 : 1);
+            const bool feeds_convt = !L.transposed && q < e->dac.size() && e->dac[q].transposed && (fused || L.k == 1 || i == 0);
+            if (feeds_convt) {
+                const ConvArgs cons = layer_args(q, T, nxt, cur);
+                if (conv_can_pack(a, cons)) { a.alpha_out = e->dac[q].alpha; packed = true; }
             }
             HIP_TRY(conv_launch(a, s));
+            if (fused) { std::swap(cur, nxt); ++i; continue; }
             if (L.transposed) { T = a.Tout; std::swap(cur, nxt); }
             else if (L.k == 1) { std::swap(cur, nxt); }   // result is in nxt (= the unit's input buffer)
             else if (!last) { std::swap(cur, nxt); }       // conv7 / conv0 result becomes current

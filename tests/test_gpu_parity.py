@@ -1239,6 +1239,40 @@ def test_dac_production_kernels_against_the_oracle_at_production_sizes(hip, name
         assert float(dw.pow(2).mean().sqrt()) < 1e-5 and float(dw.abs().max()) < 1e-4, (i, float(dw.abs().max()))
 
 
+def test_dac_transposed_convs_on_the_dma_window_kernel_equal_the_ring_kernel_bit_for_bit(hip):
+    """Round 6: the layer in front of every transposed conv (conv0, the last residual unit of blocks 1-3) applies that conv's
+    Snake and the fp16 hi / lo split ONCE per element in its epilogue and stores [hi x 8 | lo x 8] per 8-channel group in place
+    (csrc/conv.h: alpha_out / in_packed); the transposed conv then runs on convt_dma_kernel, whose activation window arrives by
+    LDS-DMA a chunk ahead instead of through registers, Snake, split, ds_write and two barriers per chunk.  Same Snake, same
+    split, same MFMA operands in the same order: the waveform must be BIT-IDENTICAL to the fp32 hand-over + ring kernel
+    (PTTS_DAC_NO_PRESPLIT=1) - at the benchmark clip length, in a batch with a ragged last row tile, and at 300 frames where conv0
+    and the first transposed conv stay on the register-staged kernel (that pair is not packed) - and a clip alone must equal the
+    same clip inside the batch."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=21, parts=("audio_encoder",))
+    g = torch.Generator().manual_seed(3)
+    for B, F in ((1, 2571), (3, 1100), (2, 300)):
+        codes = torch.randint(0, 1024, (B, 9, F), generator=g)
+        out = {}
+        for off in (False, True):
+            if off:
+                os.environ["PTTS_DAC_NO_PRESPLIT"] = "1"
+            try:
+                dac = DACModel(cfg, sd, device="cuda:0")
+                out[off] = dac.decode(codes[None], [None]).audio_values.cpu()
+                if not off and B > 1:
+                    one = dac.decode(codes[None, 1:2], [None]).audio_values.cpu()
+                    assert torch.equal(one, out[off][1:2]), (B, F)
+                del dac
+            finally:
+                os.environ.pop("PTTS_DAC_NO_PRESPLIT", None)
+            torch.cuda.empty_cache()
+        assert float(out[False].abs().max()) > 0.05 and torch.equal(out[False], out[True]), (B, F)
+
+
 # ------------------------------------------------------------------------------------------------
 # codec, encode direction (audio prompts): DAC encoder conv stack + residual vector quantiser
 # ------------------------------------------------------------------------------------------------
