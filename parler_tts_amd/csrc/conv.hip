@@ -906,6 +906,7 @@ __global__ __launch_bounds__(512) void convt_dma_kernel(ConvArgs a) {
     // `spread` (tap 0): the five window pieces of chunk c + 1 go out one per two output blocks INSIDE the MFMA loop instead of in one
     // burst behind the barrier - eight waves x eight LDS-DMA instructions in a row hold every wave's first MFMA back behind the
     // texture addresser's queue
+    half8 xfh[NI] = {}, xfl[NI] = {}, bh[3] = {}, bl[3] = {};      // fragment registers of multiply(): declared (and zeroed) once per kernel
     auto multiply = [&](int c, auto tc, int slot) {
         constexpr int t = decltype(tc)::value;
         typedef __attribute__((address_space(3))) const char lds_cchar;
@@ -915,9 +916,11 @@ __global__ __launch_bounds__(512) void convt_dma_kernel(ConvArgs a) {
         const unsigned wbase = (unsigned)(uintptr_t)(lds_cchar*)(ring + slot * UB) +
                                (unsigned)((lane & 15) * LDH + 8 * swz16(lane & 15, lane >> 4)) * 2u;
         constexpr int XL = WROWS * 64, WL = TN * LDH * 2;                        // byte distance hi plane -> lo plane
-        half8 xfh[NI], xfl[NI], bh[3], bl[3];
         static_assert(NI == 2, "two interleaved accumulator chains");
-#define PTTS_LDS_READ(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+        // "+v": the fragment registers stay LIVE between a block's MFMAs and the read that refills them, so hipcc cannot hand one of
+        // them to an MFMA as a temporary destination in between - a matrix-pipe write still retiring into a register that an
+        // inline-asm load (which the hazard recognizer does not model) is about to fill (tools/check_mfma_asm_hazard.py)
+#define PTTS_LDS_READ(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(base), "n"(off))
         PTTS_LDS_READ(xfh[0], xbase, 0);
         PTTS_LDS_READ(xfl[0], xbase, XL);
         PTTS_LDS_READ(xfh[1], xbase, 1024);
