@@ -10,8 +10,8 @@ launcher (training/run_parler_tts_training.py:1555, 1684-1689 is its multi-proce
 
 Pure stdlib on purpose: no torch, no HIP call - it runs before the process has initialised a GPU and never execs a wrapper
 (`taskset` / `numactl` in front of a GPU process is refused on the pool this is measured on).  `PTTS_NO_AFFINITY=1` opts out.
-Ranks whose GPUs share a NUMA node get DISJOINT contiguous slices of that node's cores (at least MIN_CORES each), else the
-whole node; every failure leaves the affinity alone and says why in the returned record.
+Ranks whose GPUs share a NUMA node get DISJOINT slices of that node's physical cores (both hardware threads of a core in the same
+slice; at least MIN_CORES each), else the whole node; every failure leaves the affinity alone and says why in the returned record.
 """
 from __future__ import annotations
 
@@ -104,10 +104,26 @@ def visible_gpu_indices(n_gpus: int, env: Optional[Dict[str, str]] = None) -> Li
     return idx
 
 
-def plan_affinity(slot: int, gpu_cpus: Sequence[Sequence[int]], allowed: Sequence[int], min_cores: int = MIN_CORES) -> List[int]:
+def thread_siblings(cpus: Sequence[int], sysfs: str = "/") -> Dict[int, int]:
+    """cpu -> lowest-numbered hardware thread of its physical core (itself where the topology cannot be read)"""
+    out: Dict[int, int] = {}
+    for c in cpus:
+        try:
+            with open(os.path.join(sysfs, f"sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list")) as f:
+                out[c] = min(parse_cpulist(f.read()) or [c])
+        except (OSError, ValueError):
+            out[c] = c
+    return out
+
+
+def plan_affinity(slot: int, gpu_cpus: Sequence[Sequence[int]], allowed: Sequence[int], min_cores: int = MIN_CORES,
+                  core_of: Optional[Dict[int, int]] = None) -> List[int]:
     """Cores for the rank in `slot`.  gpu_cpus[i] = cores local to the GPU of slot i (one entry per rank of this node, in rank
     order), `allowed` = what the process may use at all (cgroup cpuset).  Ranks whose GPUs have the same local cores share
-    them out in contiguous, disjoint slices by slot order; a slice under `min_cores` cores -> the whole set (equal per node)."""
+    them out in contiguous, disjoint slices by slot order; a slice under `min_cores` cores -> the whole set (equal per node).
+    `core_of` (thread_siblings) keeps the hardware threads of a physical core in ONE slice: a node lists its SMT siblings in the
+    upper half of its cpulist ("0-63,128-191"), and slicing that list by position would seat two ranks' host loops on the two
+    threads of the same cores."""
     allowed_s = set(allowed)
     mine = [c for c in gpu_cpus[slot] if c in allowed_s]
     if not mine:
@@ -115,12 +131,17 @@ def plan_affinity(slot: int, gpu_cpus: Sequence[Sequence[int]], allowed: Sequenc
     key = tuple(sorted(gpu_cpus[slot]))
     peers = [i for i, c in enumerate(gpu_cpus) if tuple(sorted(c)) == key]
     k, pos = len(peers), peers.index(slot)
-    per = len(mine) // k
-    if k == 1 or per < min_cores:
-        return mine
+    core_of = core_of or {}
+    groups: Dict[int, List[int]] = {}
+    for c in sorted(mine):
+        groups.setdefault(core_of.get(c, c), []).append(c)
+    cores = [groups[g] for g in sorted(groups)]              # physical cores, each with its allowed hardware threads
+    per = len(cores) // k
+    if k == 1 or per == 0 or sum(len(g) for g in cores[:per]) < min_cores:
+        return sorted(mine)
     lo = pos * per
-    hi = len(mine) if pos == k - 1 else lo + per
-    return mine[lo:hi]
+    hi = len(cores) if pos == k - 1 else lo + per
+    return sorted(c for g in cores[lo:hi] for c in g)
 
 
 def bind_rank_to_numa_node(local_rank: int, local_world: int = 1, gpu_of_slot: Optional[Sequence[int]] = None,
@@ -161,7 +182,7 @@ def bind_rank_to_numa_node(local_rank: int, local_world: int = 1, gpu_of_slot: O
         except (OSError, ValueError):
             pass
         allowed = sorted(os.sched_getaffinity(0))
-        want = plan_affinity(local_rank, cpus, allowed)
+        want = plan_affinity(local_rank, cpus, allowed, core_of=thread_siblings(cpus[local_rank], sysfs))
         rec["planned_cpus"] = format_cpulist(want)
         if not want:
             rec["why"] = f"none of the GPU's local cores ({format_cpulist(cpus[local_rank])}) is in this process's cpuset"

@@ -48,6 +48,15 @@ def test_planner_gives_ranks_of_one_node_disjoint_slices_and_covers_the_node():
         for b in range(a + 1, 8):
             assert not set(plans[a]) & set(plans[b])
     assert sorted(sum(plans[:4], [])) == sorted(node0) and sorted(sum(plans[4:], [])) == sorted(node1)
+    # with the SMT topology known a physical core's two threads stay in one slice (by position, ranks 0 and 2 would share cores)
+    core_of = {c: c % 128 for c in range(256)}
+    plans = [A.plan_affinity(r, gpu_cpus, allowed, core_of=core_of) for r in range(8)]
+    assert plans[0] == list(range(0, 16)) + list(range(128, 144)) and plans[3] == list(range(48, 64)) + list(range(176, 192))
+    assert plans[4] == list(range(64, 80)) + list(range(192, 208))
+    for a in range(8):
+        assert len(plans[a]) == 32 and {core_of[c] for c in plans[a]} == {core_of[c] for c in plans[a] if c < 128}
+        for b in range(a + 1, 8):
+            assert not {core_of[c] for c in plans[a]} & {core_of[c] for c in plans[b]}
     # a cpuset smaller than the node: slices of what is allowed
     plans = [A.plan_affinity(r, gpu_cpus, list(range(0, 16))) for r in range(4)]
     assert [len(p) for p in plans] == [4, 4, 4, 4] and sorted(sum(plans, [])) == list(range(16))
@@ -55,6 +64,15 @@ def test_planner_gives_ranks_of_one_node_disjoint_slices_and_covers_the_node():
     assert [A.plan_affinity(r, [[0, 1, 2, 3]] * 4, [0, 1, 2, 3]) for r in range(4)] == [[0, 1, 2, 3]] * 4
     # none of the GPU's cores allowed: nothing to bind to
     assert A.plan_affinity(0, [[8, 9]], [0, 1]) == []
+
+
+def test_thread_siblings_come_from_the_cpu_topology(tmp_path):
+    for c, sib in ((0, "0,4"), (4, "0,4"), (1, "1,5"), (5, "1,5")):
+        d = tmp_path / f"sys/devices/system/cpu/cpu{c}/topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text(sib + "\n")
+    assert A.thread_siblings([0, 1, 4, 5, 9], str(tmp_path)) == {0: 0, 4: 0, 1: 1, 5: 1, 9: 9}      # cpu9: unreadable -> itself
+    assert A.plan_affinity(1, [[0, 1, 4, 5]] * 2, [0, 1, 4, 5], core_of=A.thread_siblings([0, 1, 4, 5], str(tmp_path))) == [1, 5]
 
 
 def test_sysfs_walk_binds_this_process_and_opts_out(tmp_path, monkeypatch):
