@@ -589,7 +589,11 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
             if (c * TAPS + t < D) wait_vmcnt<K::n_min>();
             else wait_vmcnt<K::younger(t, more)>();
             STAMP(0, ts);
+#if PTTS_CONV_ABLATE == 5       // timing-only ablation (WRONG results, may read half-landed units): the tap without its workgroup barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
             lds_barrier();                                // at t = 0 also: the stashed window of chunk c is visible
+#endif
             STAMP(1, ts);
             {
                 int ps = slot + D; if (ps >= RS) ps -= RS;
