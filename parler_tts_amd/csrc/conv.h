@@ -47,7 +47,7 @@ enum {
     CONV_KIND_RING_96_T7 = 6,  // conv_kernel_h3r<96, 64, 7 | 2 | 1, 4, false>: 6, 7 (transposed), 8
     CONV_KIND_RING_96_T2 = 7,
     CONV_KIND_RING_96_T1 = 8,
-    CONV_KIND_RING_192_T7 = 9, // conv_kernel_h3r<192, 32, 7 | 2 | 1, 4, false>: 9, 10 (transposed), 11
+    CONV_KIND_RING_192_T7 = 9, // conv_kernel_h3r<192, 64, 7, 4, false, 2> (64 x 96 wave tiles) | <192, 32, 2 | 1, 4, false>: 9, 10 (transposed: convt_dma_kernel on packed input), 11
     CONV_KIND_RING_192_T2 = 10,
     CONV_KIND_RING_192_T1 = 11,
     CONV_KIND_H3 = 12,         // conv_kernel_h3 (register-staged fp16 x3 kernel)

@@ -31,6 +31,7 @@
 #define PTTS_CONV_ABLATE 0      // timing-only ablations of conv_kernel_h3r (tools/gpu_calls.md); never in the product build
 #endif
 #include <atomic>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -436,16 +437,17 @@ __device__ inline void lds_barrier() {      // own LDS writes done, then the wor
     asm volatile("" ::: "memory");
 }
 
-template <int TN, int RW, int TAPS, int RS>
+template <int TN, int RW, int TAPS, int RS, int WC = 1>
 struct H3R {
-    static constexpr int NT = TN / 16, NI = RW / 16, TMW = 8 * RW, D = RS - 1;
+    // WC = 2 (round 6): the eight waves tile the workgroup's TMW x TN outputs as 4 row groups x 2 column halves instead of 8 x 1
+    static constexpr int NT = TN / 16 / WC, NI = RW / 16, TMW = (8 / WC) * RW, D = RS - 1;
     static constexpr int UB = TN * 128;                    // bytes of one weight unit
     static constexpr int GS = 16;                          // bytes per lane and LDS-DMA instruction (12-byte pieces do not land lane x 12 apart)
     static constexpr int PI = UB / (64 * GS);              // 1 KB wave-instructions a unit needs: 8 | 12 | 16
     static constexpr int G = (PI + 7) / 8;                 // issued per wave and unit - the SAME on every wave (the vmcnt tables need that,
                                                            // and a branch around a DMA makes hipcc drain vmcnt at the next load): at TN = 96
                                                            // waves 4 .. 7 have no second piece and copy their first one again
-    static constexpr int XA = h3_xa(RW);
+    static constexpr int XA = h3_xa(TMW / 8);
     static constexpr int xs(int t) {                       // activation loads issued at tap t (+ the alpha row at tap 0)
         int n = t == 0 ? 1 : 0;
         for (int k = 0; k < XA; ++k) n += (k % TAPS == t) ? 1 : 0;
@@ -470,13 +472,21 @@ struct H3R {
 // (conv_units2_kernel) and nothing moves between lanes.  The fragments arrive as KS more units through the same ring (instead
 // of the clamped tail units).  h is neither written (8 GB per layer at C = 96) nor read back, and one launch goes away.
 // The sum over a k-step runs in another channel order than in the separate 1x1 kernel: equal to ~1e-7 relative, not bit for bit.
-template <int TN, int RW, int TAPS, int RS, bool FUSE>
+//
+// WC = 2 (round 6, the wide 7-tap convs): a wave computes 64 rows x 96 outputs instead of 32 x 192 - the same workgroup tile, ring
+// units, window and MFMA count, the same products in the same order per output (bit-identical), but 8 activation + 12 weight
+// fragment reads per tap and wave instead of 4 + 24: the CU's LDS pipe, 78 % as busy as the matrix pipe at 28 reads per 72 MFMAs,
+// gets 29 % less to do (profiles/r06_dac_pipelined_stash.txt: that stream, not the stash or the barriers, is what holds the family).
+// Not for FUSE: the 1x1 stage needs all TN channels of a row in one wave.
+template <int TN, int RW, int TAPS, int RS, bool FUSE, int WC = 1>
 __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
-    using K = H3R<TN, RW, TAPS, RS>;
+    using K = H3R<TN, RW, TAPS, RS, WC>;
     static_assert(!FUSE || (TN % 32 == 0 && RW % 32 == 0), "fused 1x1 stage: k-steps of 32 channels, row tiles in pairs");
+    static_assert(WC == 1 || (WC == 2 && !FUSE && (TN / 16) % 2 == 0), "column halves: plain conv instances only");
     constexpr int NT = K::NT, NI = K::NI, TMW = K::TMW, D = K::D, UB = K::UB, GS = K::GS, XA = K::XA;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = WC == 1 ? w : w % (8 / WC), wc = WC == 1 ? 0 : w / (8 / WC);      // the wave's row group / column part
     const int n0 = blockIdx.x * TN;
     const int u0 = blockIdx.y * TMW;
     const int b = blockIdx.z;
@@ -610,7 +620,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
             const _Float16* wh = reinterpret_cast<const _Float16*>(ring + slot * UB);
             const _Float16* wl = wh + TN * LDH;
             const int roff = t * a.tstep + a.toff - lo_r;
-            const int xrow = w * RW + roff + (lane & 15);
+            const int xrow = wr * RW + roff + (lane & 15);
             const size_t xo = (size_t)xrow * LDH + 8 * swz16(xrow, lane >> 4);     // row + 16 has the same bit 2
             half8 xfh[NI], xfl[NI];
 #pragma unroll
@@ -618,7 +628,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
                 xfh[i] = *reinterpret_cast<const half8*>(xh + xo + (size_t)i * 16 * LDH);
                 xfl[i] = *reinterpret_cast<const half8*>(xl + xo + (size_t)i * 16 * LDH);
             }
-            const size_t wo = (size_t)(lane & 15) * LDH + 8 * swz16(lane & 15, lane >> 4);
+            const size_t wo = (size_t)(wc * NT * 16 + (lane & 15)) * LDH + 8 * swz16(lane & 15, lane >> 4);   // wc * NT * 16 is a multiple of 8: the row's bit 2 is the lane's
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
 #if PTTS_CONV_ABLATE == 1       // timing-only ablation (WRONG results): one weight fragment pair per tap instead of NT
@@ -799,11 +809,11 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     const float* resb = a.res ? a.res + (size_t)b * obs : nullptr;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int u = u0 + w * RW + i * 16 + (lane & 15);
+        const int u = u0 + wr * RW + i * 16 + (lane & 15);
         if (u >= a.U) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 16 + 4 * (lane >> 4);
+            const int n = n0 + (wc * NT + j) * 16 + 4 * (lane >> 4);
             int t, co;
             if (a.stride == 1) { t = u; co = n; }
             else { const int r = n / a.Cout; co = n - r * a.Cout; t = a.stride * u - a.pad_t + r; }
@@ -1524,6 +1534,8 @@ hipError_t conv_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 7, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 64, 7, 4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 1, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1686,7 +1698,11 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                 else if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 2, RS, false>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 1, RS, false>), grid, dim3(512), lds, s, a);
             } else {
-                if (a.taps == 7) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, false>), grid, dim3(512), lds, s, a);
+                // 7 taps: 64 x 96 wave tiles (same workgroup tile, grid and LDS); PTTS_DAC_WAVE_TILE=32x192: the 32 x 192 instance (A/B, test)
+                const char* wt_now = getenv("PTTS_DAC_WAVE_TILE");
+                if (a.taps == 7 && !(wt_now && strcmp(wt_now, "32x192") == 0))
+                    hipLaunchKernelGGL((conv_kernel_h3r<192, 64, 7, RS, false, 2>), grid, dim3(512), lds, s, a);
+                else if (a.taps == 7) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, false>), grid, dim3(512), lds, s, a);
                 else if (a.taps == 2) hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 2, RS, false>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 1, RS, false>), grid, dim3(512), lds, s, a);
             }

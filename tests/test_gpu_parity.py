@@ -1273,6 +1273,37 @@ def test_dac_transposed_convs_on_the_dma_window_kernel_equal_the_ring_kernel_bit
         assert float(out[False].abs().max()) > 0.05 and torch.equal(out[False], out[True]), (B, F)
 
 
+def test_dac_wide_seven_tap_convs_on_64x96_wave_tiles_equal_the_32x192_instance_bit_for_bit(hip):
+    """Round 6: the wide residual units' 7-tap convs (C = 768, 384 at mini_v0.1) run the ring kernel with the eight waves of a
+    workgroup tiled 4 row groups x 2 column halves (conv_kernel_h3r<192, 64, 7, 4, false, WC = 2>: 64 rows x 96 outputs per
+    wave, 20 fragment reads per tap instead of 28) over the SAME workgroup tile, ring units and window as the 32 x 192 instance
+    (PTTS_DAC_WAVE_TILE=32x192).  Every output is the same sum in the same order: the waveform must be BIT-IDENTICAL - at the
+    benchmark clip length, in a batch with ragged row tiles, at short clips - and a clip alone must equal the clip in the batch."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=29, parts=("audio_encoder",))
+    g = torch.Generator().manual_seed(7)
+    for B, F in ((1, 2571), (3, 1100), (2, 300), (1, 37)):
+        codes = torch.randint(0, 1024, (B, 9, F), generator=g)
+        out = {}
+        for off in (False, True):
+            if off:
+                os.environ["PTTS_DAC_WAVE_TILE"] = "32x192"
+            try:
+                dac = DACModel(cfg, sd, device="cuda:0")
+                out[off] = dac.decode(codes[None], [None]).audio_values.cpu()
+                if not off and B > 1:
+                    one = dac.decode(codes[None, 1:2], [None]).audio_values.cpu()
+                    assert torch.equal(one, out[off][1:2]), (B, F)
+                del dac
+            finally:
+                os.environ.pop("PTTS_DAC_WAVE_TILE", None)
+            torch.cuda.empty_cache()
+        assert float(out[False].abs().max()) > 0.05 and torch.equal(out[False], out[True]), (B, F)
+
+
 # ------------------------------------------------------------------------------------------------
 # codec, encode direction (audio prompts): DAC encoder conv stack + residual vector quantiser
 # ------------------------------------------------------------------------------------------------
