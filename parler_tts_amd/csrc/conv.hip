@@ -162,6 +162,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#ifdef PTTS_CONV_LIFE
+// diagnostic build (-DPTTS_CONV_LIFE; no stamp inside the chunk loop): what a ring-kernel workgroup spends before its first tap, in
+// its chunk loop and behind it, in s_memrealtime ticks (10 ns): [0] prologue [1] chunk loop [2] stage 2 + epilogue [3] workgroups
+__device__ unsigned long long g_conv_life[4];
+#define LIFE(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#else
+#define LIFE(var) do { } while (0)
+#endif
 #ifdef PTTS_CONV_STAMPS
 // diagnostic build (make CXXFLAGS+=-DPTTS_CONV_STAMPS): wave 0 of every workgroup adds the cycles of each phase of the chunk loop
 // [0] fetch issue  [1] MFMA loop  [2] barrier after it  [3] stash  [4] barrier before the next chunk  [5] chunks  [6] whole kernel
@@ -486,6 +494,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     constexpr int NT = K::NT, NI = K::NI, TMW = K::TMW, D = K::D, UB = K::UB, GS = K::GS, XA = K::XA;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LIFE(life0);
     const int wr = WC == 1 ? w : w % (8 / WC), wc = WC == 1 ? 0 : w / (8 / WC);      // the wave's row group / column part
     const int n0 = blockIdx.x * TN;
     const int u0 = blockIdx.y * TMW;
@@ -587,6 +596,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};       // [0] DMA wait [1] tap barrier [2] issue [3] MFMA [4] chunk barrier [5] stash
     unsigned long long nchunk_done = 0;
 #endif
+    LIFE(life1);
     int slot = 0;                                         // ring slot of the unit about to be consumed
     // one chunk: MORE = the next chunk exists (its activation loads ride on the taps); the last chunk is peeled so that the loop
     // body has no conditional loads (hipcc would otherwise merge "loads may be pending" into the loop head and drain vmcnt)
@@ -661,6 +671,17 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     };
     for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::true_type{});
     chunk(nchunks - 1, std::false_type{});
+    LIFE(life2);
+#ifdef PTTS_CONV_LIFE
+    auto life_end = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left: what a successor workgroup on this CU waits for at least
+        const unsigned long long life3 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicAdd(&g_conv_life[0], life1 - life0); atomicAdd(&g_conv_life[1], life2 - life1);
+            atomicAdd(&g_conv_life[2], life3 - life2); atomicAdd(&g_conv_life[3], 1ull);
+        }
+    };
+#endif
 #ifdef PTTS_CONV_STAMPS
     if (tid == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_stamps[8 + i], tacc[i]);
@@ -800,6 +821,9 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
 #pragma unroll
             for (int ii = 0; ii < NI; ++ii) store_tile(ii, acc2[ii]);
         }
+#ifdef PTTS_CONV_LIFE
+        life_end();
+#endif
         return;
     }
 
@@ -829,6 +853,9 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
             else *reinterpret_cast<float4*>(outb + (size_t)t * a.Cout + co) = y;
         }
     }
+#ifdef PTTS_CONV_LIFE
+    life_end();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1572,7 +1599,33 @@ void conv_kernel_counts(long long* out, int n, bool reset) {
     if (reset) for (int i = 0; i < CONV_KIND_COUNT; ++i) g_conv_counts[i].store(0, std::memory_order_relaxed);
 }
 
-#ifdef PTTS_CONV_STAMPS
+#ifdef PTTS_CONV_LIFE
+static hipError_t conv_launch_inner(const ConvArgs& a, hipStream_t s);
+hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
+    if (g_conv_plan) return conv_launch_inner(a, s);
+    unsigned long long z[4] = {0, 0, 0, 0};
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_life), z, sizeof(z));
+    (void)hipEventRecord(e0, s);
+    const hipError_t e = conv_launch_inner(a, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipStreamSynchronize(s);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_conv_life), sizeof(z));
+    if (z[3]) {
+        const double n = (double)z[3], life = (z[0] + z[1] + z[2]) / n * 0.01, slot_us = ms * 1e3 * (n < 256 ? n : 256.0) / n;
+        fprintf(stderr, "ring life Cin=%d N=%d taps=%d dil=%d U=%d fused=%d: %.0f workgroups, kernel %.3f ms = %.1f us per workgroup slot | prologue %.2f us, "
+                "chunk loop %.2f, stage 2 + epilogue + store drain %.2f, life %.2f -> between workgroups %.2f us\n", a.Cin, a.N, a.taps,
+                a.tstep, a.U, a.w2_units ? 1 : 0, n, ms, slot_us, z[0] / n * 0.01, z[1] / n * 0.01, z[2] / n * 0.01, life, slot_us - life);
+    }
+    return e;
+}
+static hipError_t conv_launch_inner(const ConvArgs& a, hipStream_t s) {
+#elif defined(PTTS_CONV_STAMPS)
 static hipError_t conv_launch_inner(const ConvArgs& a, hipStream_t s);
 hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
     unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1761,7 +1814,7 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
 int conv_kind_of(const ConvArgs& a) {
     int kind = -1;
     g_conv_plan = &kind;
-#ifdef PTTS_CONV_STAMPS
+#if defined(PTTS_CONV_STAMPS) || defined(PTTS_CONV_LIFE)
     (void)conv_launch_inner(a, nullptr);
 #else
     (void)conv_launch(a, nullptr);
