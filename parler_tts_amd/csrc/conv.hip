@@ -445,17 +445,18 @@ __device__ inline void lds_barrier() {      // own LDS writes done, then the wor
     asm volatile("" ::: "memory");
 }
 
-template <int TN, int RW, int TAPS, int RS, int WC = 1>
+template <int TN, int RW, int TAPS, int RS, int WC = 1, int NW = 8>
 struct H3R {
     // WC = 2 (round 6): the eight waves tile the workgroup's TMW x TN outputs as 4 row groups x 2 column halves instead of 8 x 1
-    static constexpr int NT = TN / 16 / WC, NI = RW / 16, TMW = (8 / WC) * RW, D = RS - 1;
+    // NW = 4 (round 6): four-wave workgroups, two of them on a CU (fused unit at C = 96)
+    static constexpr int NT = TN / 16 / WC, NI = RW / 16, TMW = (NW / WC) * RW, D = RS - 1;
     static constexpr int UB = TN * 128;                    // bytes of one weight unit
     static constexpr int GS = 16;                          // bytes per lane and LDS-DMA instruction (12-byte pieces do not land lane x 12 apart)
     static constexpr int PI = UB / (64 * GS);              // 1 KB wave-instructions a unit needs: 8 | 12 | 16
-    static constexpr int G = (PI + 7) / 8;                 // issued per wave and unit - the SAME on every wave (the vmcnt tables need that,
+    static constexpr int G = (PI + NW - 1) / NW;           // issued per wave and unit - the SAME on every wave (the vmcnt tables need that,
                                                            // and a branch around a DMA makes hipcc drain vmcnt at the next load): at TN = 96
                                                            // waves 4 .. 7 have no second piece and copy their first one again
-    static constexpr int XA = h3_xa(TMW / 8);
+    static constexpr int XA = NW == 8 ? h3_xa(TMW / 8) : (TMW + 64) * (KC3 / 4) / (NW * 64);      // NW = 4: span <= 64
     static constexpr int xs(int t) {                       // activation loads issued at tap t (+ the alpha row at tap 0)
         int n = t == 0 ? 1 : 0;
         for (int k = 0; k < XA; ++k) n += (k % TAPS == t) ? 1 : 0;
@@ -486,16 +487,18 @@ struct H3R {
 // fragment reads per tap and wave instead of 4 + 24: the CU's LDS pipe, 78 % as busy as the matrix pipe at 28 reads per 72 MFMAs,
 // gets 29 % less to do (profiles/r06_dac_pipelined_stash.txt: that stream, not the stash or the barriers, is what holds the family).
 // Not for FUSE: the 1x1 stage needs all TN channels of a row in one wave.
-template <int TN, int RW, int TAPS, int RS, bool FUSE, int WC = 1>
-__global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
-    using K = H3R<TN, RW, TAPS, RS, WC>;
+template <int TN, int RW, int TAPS, int RS, bool FUSE, int WC = 1, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_kernel_h3r(ConvArgs a) {
+    using K = H3R<TN, RW, TAPS, RS, WC, NW>;
+    constexpr int NTH = 64 * NW, RPP = NTH / (KC3 / 4);       // threads; window rows one staging piece covers
+    static_assert(NW == 8 || (NW == 4 && WC == 1 && K::PI % NW == 0), "four-wave workgroups: every wave copies PI / 4 pieces of a unit");
     static_assert(!FUSE || (TN % 32 == 0 && RW % 32 == 0), "fused 1x1 stage: k-steps of 32 channels, row tiles in pairs");
     static_assert(WC == 1 || (WC == 2 && !FUSE && (TN / 16) % 2 == 0), "column halves: plain conv instances only");
     constexpr int NT = K::NT, NI = K::NI, TMW = K::TMW, D = K::D, UB = K::UB, GS = K::GS, XA = K::XA;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     LIFE(life0);
-    const int wr = WC == 1 ? w : w % (8 / WC), wc = WC == 1 ? 0 : w / (8 / WC);      // the wave's row group / column part
+    const int wr = WC == 1 ? w : w % (NW / WC), wc = WC == 1 ? 0 : w / (NW / WC);      // the wave's row group / column part
     const int n0 = blockIdx.x * TN;
     const int u0 = blockIdx.y * TMW;
     const int b = blockIdx.z;
@@ -524,12 +527,12 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
     float4 alr = make_float4(0, 0, 0, 0);
     const int xq = tid % (KC3 / 4), xrow0 = tid / (KC3 / 4);
     const unsigned xbase = (unsigned)(u0 + lo_r + xrow0) * (unsigned)a.Cin + 4 * xq;     // wraps for rows < 0: masked by xvalid
-    const unsigned xstep = 64u * (unsigned)a.Cin;
+    const unsigned xstep = (unsigned)RPP * (unsigned)a.Cin;
     unsigned xvalid = 0;
 #pragma unroll
     for (int k = 0; k < XA; ++k) {
-        const int t = u0 + lo_r + xrow0 + 64 * k;
-        xvalid |= (tid + 512 * k < nx && t >= 0 && t < a.Tin) ? 1u << k : 0u;
+        const int t = u0 + lo_r + xrow0 + RPP * k;
+        xvalid |= (tid + NTH * k < nx && t >= 0 && t < a.Tin) ? 1u << k : 0u;
     }
     auto xload = [&](int k, int c0) {
         const unsigned off = (xvalid >> k) & 1 ? xbase + k * xstep : 0u;
@@ -540,8 +543,8 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
         const float4 inv = make_float4(1.0f / (alr.x + 1e-9f), 1.0f / (alr.y + 1e-9f), 1.0f / (alr.z + 1e-9f), 1.0f / (alr.w + 1e-9f));
 #pragma unroll
         for (int k = 0; k < XA; ++k) {
-            if (tid + 512 * k < nx) {
-                const int r = xrow0 + 64 * k;
+            if (tid + NTH * k < nx) {
+                const int r = xrow0 + RPP * k;
                 float4 v = (xvalid >> k) & 1 ? xr[k] : make_float4(0, 0, 0, 0);
 #if PTTS_CONV_ABLATE != 3       // 3 = timing-only ablation (WRONG results): the stash without Snake
                 if (snake) {   // Snake(0) = 0, so the zero padding needs no special case
@@ -568,14 +571,14 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
 #if defined(PTTS_RING_DEBUG_COPY)         // diagnostic build: the same pieces moved through registers (tells a layout bug from a DMA one)
 #pragma unroll
         for (int j = 0; j < K::G; ++j) {
-            const int o = w + 8 * j < K::PI ? j * 512 * GS : 0;
+            const int o = w + NW * j < K::PI ? j * NTH * GS : 0;
             *reinterpret_cast<uint4*>(dst + o + lane * GS) = *reinterpret_cast<const uint4*>(src + o);
         }
 #elif defined(__HIP_DEVICE_COMPILE__)      // the builtin does not exist in the host pass, which would then drop the kernel's launch stub
         typedef __attribute__((address_space(3))) void lds_void;
 #pragma unroll
         for (int j = 0; j < K::G; ++j) {
-            const int o = w + 8 * j < K::PI ? j * 512 * GS : 0;
+            const int o = w + NW * j < K::PI ? j * NTH * GS : 0;
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src + o), (lds_void*)(dst + o), 16, 0, 0);
         }
 #else
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
         float* ivs = als + TN;
         float* als_o = ivs + TN;                          // [TN] / [TN]: the same pair for the CONSUMER's Snake when the output goes out packed
         float* ivs_o = als_o + TN;
-        for (int i = tid; i < TN; i += 512) {
+        for (int i = tid; i < TN; i += NTH) {
             const float al = a.alpha2[i]; als[i] = al; ivs[i] = 1.0f / (al + 1e-9f);
             if (a.alpha_out) { const float ao = a.alpha_out[i]; als_o[i] = ao; ivs_o[i] = 1.0f / (ao + 1e-9f); }
         }
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(512) void conv_kernel_h3r(ConvArgs a) {
             }
         } else {
             // more stage-2 units than the ring holds: they keep streaming, one k-step per ring step, every row tile accumulates
-            static_assert(NI == 2, "streamed stage 2 keeps a second accumulator set for every row tile");
+            static_assert(NI == 2 || NW == 4, "streamed stage 2 keeps a second accumulator set for every row tile");
             f32x4 acc2[NI][NT];
 #pragma unroll
             for (int ii = 0; ii < NI; ++ii)
@@ -1555,6 +1558,8 @@ hipError_t conv_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(convt_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 3, true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<96, 64, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel_h3r<192, 32, 7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1714,7 +1719,15 @@ hipError_t conv_launch(const ConvArgs& a, hipStream_t s) {
                     return hipErrorInvalidValue;
                 PTTS_CONV_PICK(a.unit_tn == 96 ? CONV_KIND_FUSED_96 : CONV_KIND_FUSED_192);
                 PTTS_CONV_PACK_GUARD(CONV_KIND_FUSED_96);
-                if (a.unit_tn == 96) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
+                // C = 96: four-wave workgroups over 256 rows, ring of 3 + window = 76 KB: TWO on a CU, so that one's prologue, second
+                // stage and epilogue (39 % of a CU slot as one eight-wave workgroup, profiles/r06_dac_workgroup_life.txt) run beside the
+                // other's chunk loop.  PTTS_DAC_FUSED96_WAVES=8: the eight-wave workgroup over 512 rows (rounds 3-5; A/B and test)
+                const char* f96 = getenv("PTTS_DAC_FUSED96_WAVES");
+                if (a.unit_tn == 96 && span <= 64 && !(f96 && atoi(f96) == 8)) {
+                    const size_t lds4 = (size_t)(256 + span) * 128 + (size_t)3 * 96 * 128;
+                    dim3 grid4(1, (a.U + 255) / 256, a.B);
+                    hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, 3, true, 1, 4>), grid4, dim3(256), lds4, s, a);
+                } else if (a.unit_tn == 96) hipLaunchKernelGGL((conv_kernel_h3r<96, 64, 7, RS, true>), grid, dim3(512), lds, s, a);
                 else hipLaunchKernelGGL((conv_kernel_h3r<192, 32, 7, RS, true>), grid, dim3(512), lds, s, a);
                 tally(a.unit_tn == 96 ? CONV_KIND_FUSED_96 : CONV_KIND_FUSED_192);
                 return hipGetLastError();

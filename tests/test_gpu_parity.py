@@ -1304,6 +1304,38 @@ def test_dac_wide_seven_tap_convs_on_64x96_wave_tiles_equal_the_32x192_instance_
         assert float(out[False].abs().max()) > 0.05 and torch.equal(out[False], out[True]), (B, F)
 
 
+def test_dac_fused_unit_at_96_channels_on_four_wave_workgroups_equals_the_eight_wave_one_bit_for_bit(hip):
+    """Round 6: the fused residual units of the last block (C = 96) run as FOUR-wave workgroups over 256 rows with a ring of 3 -
+    76 KB of LDS, two workgroups on a CU, so that one's prologue, second stage and epilogue run beside the other's chunk loop
+    (conv_kernel_h3r<96, 64, 7, 3, true, 1, NW = 4>) - instead of one eight-wave workgroup over 512 rows
+    (PTTS_DAC_FUSED96_WAVES=8).  A wave computes the same 64 x 96 outputs from the same operands in the same order (the second
+    stage streams its three k-steps instead of holding them): the waveform must be BIT-IDENTICAL at the benchmark clip length, in a
+    batch with ragged row tiles, at short clips; and a clip alone must equal the clip in the batch."""
+    from parler_tts_amd.modeling import DACModel
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = config_for("dac_mini")
+    sd = synthetic_state_dict(cfg, seed=37, parts=("audio_encoder",))
+    g = torch.Generator().manual_seed(13)
+    for B, F in ((1, 2571), (3, 1100), (2, 300), (1, 37)):
+        codes = torch.randint(0, 1024, (B, 9, F), generator=g)
+        out = {}
+        for off in (False, True):
+            if off:
+                os.environ["PTTS_DAC_FUSED96_WAVES"] = "8"
+            try:
+                dac = DACModel(cfg, sd, device="cuda:0")
+                out[off] = dac.decode(codes[None], [None]).audio_values.cpu()
+                if not off and B > 1:
+                    one = dac.decode(codes[None, 1:2], [None]).audio_values.cpu()
+                    assert torch.equal(one, out[off][1:2]), (B, F)
+                del dac
+            finally:
+                os.environ.pop("PTTS_DAC_FUSED96_WAVES", None)
+            torch.cuda.empty_cache()
+        assert float(out[False].abs().max()) > 0.05 and torch.equal(out[False], out[True]), (B, F)
+
+
 # ------------------------------------------------------------------------------------------------
 # codec, encode direction (audio prompts): DAC encoder conv stack + residual vector quantiser
 # ------------------------------------------------------------------------------------------------
