@@ -1088,19 +1088,32 @@ __global__ __launch_bounds__(512) void conv_kernel_s1(ConvArgs a) {
         if (u > a.Tin - 1) u = a.Tin - 1;
         xrow[i] = inb + (size_t)u * a.Cin + 8 * g;
     }
-    float4 xs[2][NI][2];                                   // [register set][row tile][two float4 = 8 channels]
+    // Round 6: the activation loads are inline asm with counted waits.  As compiler-visible loads the first use of a loaded register
+    // got `s_waitcnt vmcnt(0)` (hipcc does not count through LDS-DMA instructions): at the END of every step the wave drained the
+    // loads AND the weight units it had issued at the START of that same step - a full memory round trip inside every 72-MFMA step,
+    // waves parked 60 % of their cycles, matrix pipe busy 0.23-0.33 (profiles/r06_pmc_dac.txt).  Now chunk c + 2's rows are requested
+    // at the start of step c and awaited at the end of step c + 1 with `vmcnt(XL + G)`: only the unit and the rows issued since stay in
+    // flight.  ("+v": the registers stay live, no spill / copy between the load and its wait; the kernel has no scratch.)
+    constexpr int XL = 2 * NI;                             // load instructions per xload
+    f32x4 xs[2][NI][2] = {};                               // [register set][row tile][two quads = 8 channels]
     auto xload = [&](auto setc, int c) {
         constexpr int S = decltype(setc)::value;
         const int cc = c < nchunks ? c : nchunks - 1;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            xs[S][i][0] = *reinterpret_cast<const float4*>(xrow[i] + cc * KC3);
-            xs[S][i][1] = *reinterpret_cast<const float4*>(xrow[i] + cc * KC3 + 4);
+            const float* p = xrow[i] + cc * KC3;
+            f32x4 &q0 = xs[S][i][0], &q1 = xs[S][i][1];   // (named first: an asm operand inside a generic lambda does not capture)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(q0) : "v"(p) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "+v"(q1) : "v"(p) : "memory");
         }
     };
     half8 fh[NI], fl[NI];                                  // B fragments of the chunk about to be multiplied
-    auto prepare = [&](auto setc, int c) {                 // Snake + split of chunk c (register set S) into fh / fl
+    auto prepare = [&](auto setc, int c, auto youngerc) {  // Snake + split of chunk c (register set S) into fh / fl
         constexpr int S = decltype(setc)::value;
+        static_assert(NI == 2, "the wait below names the set's four registers");
+        // the set's loads have landed when at most `younger` operations issued after them are outstanding (loads and LDS-DMA retire in order)
+        f32x4 &w0 = xs[S][0][0], &w1 = xs[S][0][1], &w2 = xs[S][1][0], &w3 = xs[S][1][1];
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "n"(decltype(youngerc)::value));
         const int cc = c < nchunks ? c : nchunks - 1;
         f32x4 al0 = {0, 0, 0, 0}, al1 = {0, 0, 0, 0}, iv0 = {0, 0, 0, 0}, iv1 = {0, 0, 0, 0};
         if (snake) {
@@ -1109,8 +1122,8 @@ __global__ __launch_bounds__(512) void conv_kernel_s1(ConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const float x8[8] = {xs[S][i][0].x, xs[S][i][0].y, xs[S][i][0].z, xs[S][i][0].w,
-                                 xs[S][i][1].x, xs[S][i][1].y, xs[S][i][1].z, xs[S][i][1].w};
+            const float x8[8] = {xs[S][i][0][0], xs[S][i][0][1], xs[S][i][0][2], xs[S][i][0][3],
+                                 xs[S][i][1][0], xs[S][i][1][1], xs[S][i][1][2], xs[S][i][1][3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float y = snake ? snake_f(x8[e], e < 4 ? al0[e] : al1[e - 4], e < 4 ? iv0[e] : iv1[e - 4]) : x8[e];
@@ -1134,15 +1147,16 @@ __global__ __launch_bounds__(512) void conv_kernel_s1(ConvArgs a) {
     xload(std::integral_constant<int, 0>{}, 0);
     xload(std::integral_constant<int, 1>{}, 1);
     lds_barrier();                                        // the table
-    prepare(std::integral_constant<int, 0>{}, 0);
+    prepare(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, XL>{});      // chunk 1's rows may still fly
 #pragma unroll
     for (int v = 0; v < D; ++v) dma(v);
 
     int slot = 0;
     auto step = [&](int c, auto parc) {
         constexpr int P = decltype(parc)::value;           // c % 2: chunk c was loaded into set P, chunk c + 1 sits in set 1 - P
-        if (c < D) wait_vmcnt<G * (D - 1)>();             // own pieces of unit c landed (a lower bound on the younger operations)
-        else wait_vmcnt<G * (D - 1)>();
+        // own pieces of unit c: step 0 waits for them itself (younger: units 1 .. D - 1); from step 1 on the wait at the end of the
+        // step before (vmcnt <= XL + G, for rows issued BEHIND unit c) has already covered them
+        if (c == 0) wait_vmcnt<G * (D - 1)>();
         lds_barrier();                                    // everyone's pieces of unit c are in LDS, everyone is done reading unit c - 1
         dma(c + D);
         xload(std::integral_constant<int, P>{}, c + 2);   // set P is free: chunk c is in fh / fl
@@ -1162,7 +1176,9 @@ __global__ __launch_bounds__(512) void conv_kernel_s1(ConvArgs a) {
             }
         }
         if (++slot == RS) slot = 0;
-        prepare(std::integral_constant<int, 1 - P>{}, c + 1);     // behind the MFMAs: the next chunk's fragments
+        // behind the MFMAs: the next chunk's fragments.  Its rows went out at the start of step c - 1 (step 0: in the prologue, which is
+        // further back still); issued since: this step's unit and rows
+        prepare(std::integral_constant<int, 1 - P>{}, c + 1, std::integral_constant<int, XL + G>{});
     };
     for (int c = 0; c < nchunks; c += 2) {
         step(c, std::integral_constant<int, 0>{});
