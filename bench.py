@@ -830,7 +830,7 @@ def main():
             },
         }
         # the weakest part of the step on the record next to the strongest: everything but the self-attention launches
-        # (6 projection / cross-attention launches per layer + heads, embed, select, advance) streams the decoder weights and
+        # (6 projection / cross-attention launches per layer + heads, embed, select) streams the decoder weights and
         # the cross K/V once per step; its time = the loop's per-step time minus layers x the self-attention launch average
         if phase["decode_ms"] and prof.launches:
             dec = cfg.decoder

@@ -211,6 +211,7 @@ struct ptts_engine {
     hipGraphExec_t step_graph = nullptr;
     ptts_sampling graph_sp = {};
     bool no_graph = false;
+    bool eager_advance = false;  // PTTS_EAGER_ADVANCE=1: a replayed step ends with advance_kernel (rounds 1-5) instead of leaving the state to the next embedding launch
     // debug: stop issuing kernels after dbg_stop launches of the current API call (-1 = off)
     int dbg_stop = -1, dbg_count = 0;
 #ifdef PTTS_STAMPS
@@ -582,6 +583,7 @@ EmbedArgs embed_args(ptts_engine* e) {
     a.pos_table = e->pos_table; a.tok_in = e->tok_in; a.prompt_table = e->embed_prompts;
     a.prompt_ids = e->prompt_ids; a.prompt_embeds = e->prompt_embeds; a.P = e->P; a.state = e->state; a.x = e->x;
     a.xfrag = e->fold_ln ? e->x_frag : nullptr;     // a step / prompt position always starts in the first buffer
+    a.unfinished = e->unfinished; a.n_latch = e->B * e->cfg.codebooks;   // the codebook embedding launch also settles the loop state
     return a;
 }
 
@@ -611,7 +613,9 @@ int run_forward_half(ptts_engine* e, hipStream_t s, bool profile) {
 }
 
 // selection half: warpers / argmax / draw, pad-out, EOS latch, delay-pattern feed, loop-state advance
-int run_select_half(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
+// `settle` = false leaves the loop state to the next step's embedding launch (replayed steps: ptts_decode_steps settles it once
+// behind the last replay of a call); every C-ABI entry point returns with the state settled
+int run_select_half(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool settle = true) {
     const ptts_config& c = e->cfg;
     SelectArgs sa;
     sa.logits = e->logits; sa.rows = e->B * c.codebooks; sa.V = e->Vp; sa.vocab = c.vocab; sa.L = e->L; sa.state = e->state;
@@ -624,11 +628,11 @@ int run_select_half(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
     sa.temperature = sp.temperature; sa.guidance = sp.guidance_scale; sa.seed = sp.seed;
     sa.top_p = (sp.top_p > 0.f && sp.top_p < 1.f) ? sp.top_p : 1.0f;
     HIP_TRY(select_launch(sa, s));
-    HIP_TRY(advance_launch(e->state, e->unfinished, sa.rows, e->L, s));   // pos / cur_len / step_count / unfinished count
+    if (settle) HIP_TRY(advance_launch(e->state, e->unfinished, sa.rows, e->L, s));   // pos / cur_len / step_count / unfinished count
     return PTTS_OK;
 }
 
-int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool profile) {
+int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool profile, bool settle = true) {
     EventPair* step_ev = nullptr;
     if (profile && e->ev_used < e->ev_pool.size()) {
         step_ev = &e->ev_pool[e->ev_used++];
@@ -636,7 +640,7 @@ int run_decode_step(ptts_engine* e, const ptts_sampling& sp, hipStream_t s, bool
         HIP_TRY(hipEventRecord(step_ev->a, s));
     }
     PTTS_TRY(run_forward_half(e, s, profile));
-    PTTS_TRY(run_select_half(e, sp, s));
+    PTTS_TRY(run_select_half(e, sp, s, settle));
     if (step_ev) HIP_TRY(hipEventRecord(step_ev->b, s));
     return PTTS_OK;
 }
@@ -658,7 +662,7 @@ int capture_step_graph(ptts_engine* e, const ptts_sampling& sp, hipStream_t s) {
     drop_graph(e);
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int r = run_decode_step(e, sp, s, false);
+    int r = run_decode_step(e, sp, s, false, e->eager_advance);
     hipError_t ce = hipStreamEndCapture(s, &graph);
     if (r != PTTS_OK) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -900,6 +904,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     e->layers.resize(cfg->layers);
     e->t5.resize(cfg->t5_layers > 0 ? cfg->t5_layers : 0);
     e->no_graph = getenv("PTTS_NO_GRAPH") != nullptr;
+    e->eager_advance = getenv("PTTS_EAGER_ADVANCE") != nullptr;
     // LayerNorm rows wider than the LDS-resident stage (2048 bf16 / 1024 f32 elements; BASELINE configs[4] has 1536) can
     // only take the folded form, which reads the rows as fragments and has no width limit (M:402-413 has none either)
     const bool wide_rows = cfg->hidden > (cfg->dtype == PTTS_DTYPE_BF16 ? 2048 : 1024);
@@ -1029,7 +1034,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->tok_in, sizeof(int) * rows * K);
     A(e->unfinished, sizeof(int) * (rows * K + 32));     // + 32: the attention kernel reads 16 flags from an utterance's first one, whatever K is
     A(e->force, sizeof(long long) * rows * K);
-    A(e->state, sizeof(StepState));
+    A(e->state, 2 * sizeof(StepState));      // [0] the loop state, [1] the counters the last selection left for the next step
     e->fuse_qkv_attn = getenv("PTTS_NO_FUSED_QKV_ATTN") == nullptr;
     e->fuse_arrive_ints = fused_arrive_ints(cfg->layers, e->mtiles, cfg->heads) + 32;
     A(e->fuse_arrive, sizeof(int) * e->fuse_arrive_ints);          // the last 32 ints: the error word (own line)
@@ -1053,7 +1058,7 @@ int ptts_create(const ptts_config* cfg, ptts_engine** out) {
     tab.resize(Bm * e->cross_blocks);
     for (size_t i = 0; i < tab.size(); ++i) tab[i] = (int)i;
     if (he == hipSuccess) he = hipMemcpy(e->cross_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (he == hipSuccess) he = hipMemset(e->state, 0, sizeof(StepState));
+    if (he == hipSuccess) he = hipMemset(e->state, 0, 2 * sizeof(StepState));
     if (he == hipSuccess) he = hipMemset(e->attn_frag, 0, e->esz * rows * D);
     if (he == hipSuccess) he = hipMemset(e->x_frag, 0, e->esz * rows * D);
     if (he == hipSuccess) he = hipMemset(e->x_frag2, 0, e->esz * rows * D);
@@ -1450,6 +1455,7 @@ int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, 
     if (n_steps > remaining) n_steps = remaining;
     e->dbg_count = 0;
     const bool forced = e->use_force;
+    bool unsettled = false;     // the last step was a replay, whose loop state the NEXT step's embedding launch would settle
     for (int i = 0; i < n_steps; ++i) {
         const bool prof = profile_every > 0 && ((e->host_cur - 1) % profile_every == 0);
         if (prof && e->ev_used + 2 * (size_t)e->cfg.layers + 2 > e->ev_pool.size()) {
@@ -1465,13 +1471,16 @@ int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, 
         }
         if (prof || e->no_graph || forced || e->dbg_stop >= 0) {
             PTTS_TRY(run_decode_step(e, *sp, s, prof));
+            unsettled = false;
         } else {
             if (!e->step_graph || !same_sampling(e->graph_sp, *sp)) PTTS_TRY(capture_step_graph(e, *sp, s));
             HIP_TRY(hipGraphLaunch(e->step_graph, s));
+            unsettled = !e->eager_advance;
         }
         e->host_pos += 1;
         e->host_cur += 1;
     }
+    if (unsettled) HIP_TRY(advance_launch(e->state, e->unfinished, e->B * e->cfg.codebooks, e->L, s));
     return leave_stream(e, stream, s);
 }
 

@@ -12,7 +12,9 @@ struct EmbedArgs {
     const long long* prompt_ids = nullptr;  // [B][P]
     const float* prompt_embeds = nullptr;   // [B][P][D] fp32 pre-embedded prompts (override the table lookup), or null
     int P = 0;
-    const StepState* state = nullptr;
+    StepState* state = nullptr;          // [2]: the loop state and the counters the last selection wrote for the next step (ptts_common.h)
+    const int* unfinished = nullptr;     // [n_latch] EOS latches: embed_codebooks_launch settles the loop state from them (null: it does not)
+    int n_latch = 0;
     float* x = nullptr;                  // [B][D] residual stream
     void* xfrag = nullptr;               // optional fragment-layout copy of x (weight dtype) for the folded LayerNorm path
 };
@@ -48,6 +50,8 @@ hipError_t embed_prompt_rows_launch(const EmbedArgs& a, int B, int npos, int pos
 hipError_t embed_prefix_rows_launch(const EmbedArgs& a, int B, int npos, int pos0, int col0, const long long* raw_ids,
                                     const long long* pattern, int rows_src, int L, int dtype, hipStream_t s);
 hipError_t select_launch(const SelectArgs& a, hipStream_t s);
+// settles st[0] from st[1] (the counters select_launch left for the next step) and the latches; idempotent, and the first
+// workgroup past the utterances of embed_codebooks_launch does the same thing at the head of the next step
 hipError_t advance_launch(StepState* st, const int* unfinished, int rows, int L, hipStream_t s);
 hipError_t init_tokens_launch(const long long* raw_ids, const long long* pattern, int* tok_in, int rows, int rows_eff,
                               int L, int col, hipStream_t s);

@@ -22,14 +22,43 @@ template <> struct Vec4<PF32> {
     }
 };
 
+// The loop state is settled LAZILY (round 6): the selection leaves the next step's counters in state[1] and this step's EOS
+// latches in `unfinished`; state[0] - what every other kernel of a step reads - is brought up to date from them either by
+// advance_kernel (eager steps, and once behind the last replay of a ptts_decode_steps call) or by the one workgroup past the
+// utterances of the NEXT step's embedding launch, which runs beside the row gathers instead of as a launch of its own between
+// two steps.  Same assignments in both places, and idempotent: settling twice, or with nothing selected in between, changes nothing.
+__device__ inline void settle_state(StepState* s, const int* unfinished, int rows) {
+    __shared__ int part[4];
+    int n = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) n += unfinished[r] ? 1 : 0;
+    n = (int)wave_sum((float)n);              // rows <= 2^24: exact in fp32
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int unf_total = part[0] + part[1] + part[2] + part[3];
+        // scalar_load invariant: neither kernel that settles the state writes state[1] (select_kernel and the prefill kernels do)
+        const int pos = scalar_load_int(&s[1].pos), cur = scalar_load_int(&s[1].cur_len), steps = scalar_load_int(&s[1].step_count);
+        s[0].pos = pos;
+        s[0].cur_len = cur;
+        s[0].step_count = steps;
+        s[0].n_unfinished = unf_total;
+        if (unf_total == 0 && s[0].done_len == 0) s[0].done_len = cur;
+    }
+}
+
 template <typename P>
 __global__ __launch_bounds__(256) void embed_codebooks_kernel(EmbedArgs a) {
     typedef typename P::elem_t elem_t;
     const int b = blockIdx.x;
+    if (b == (int)gridDim.x - 1 && a.unfinished) {   // the extra workgroup (uniform branch): the loop state of this step
+        settle_state(a.state, a.unfinished, a.n_latch);
+        return;
+    }
     // the step's position and this utterance's K token ids are uniform per workgroup: scalar-cache reads (no vector round trip,
     // no LDS hand-over, no barrier in front of the row gathers)
-    // scalar_load invariant (ptts_common.h): the embed kernel writes neither StepState nor tok_in (advance / select do, a launch earlier)
-    const int pos = scalar_load_int(&a.state->pos);
+    // scalar_load invariant (ptts_common.h): the embed kernel writes neither state[1] nor tok_in (select does, a launch earlier);
+    // state[0] is written by this launch's extra workgroup, so the position comes from state[1], which holds the same value
+    const int pos = scalar_load_int(&a.state[1].pos);
     int toks[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) toks[k] = k < a.K ? scalar_load_int(a.tok_in + b * a.K + k) : 0;
@@ -81,12 +110,12 @@ __global__ void embed_prompt_kernel(EmbedArgs a) {
     }
 }
 
-__global__ void advance_prompt_kernel(StepState* s) { s->pos += 1; }
+__global__ void advance_prompt_kernel(StepState* s) { const int p = s[0].pos + 1; s[0].pos = p; s[1].pos = p; }
 
 // loop state of a new call, written on the device (a hipMemcpyAsync from the host's stack needed a stream synchronisation behind
 // it - three of them per prefill, each one an idle device and a cold launch queue in front of the next phase)
 __global__ void reset_state_kernel(StepState* s, StepState v, int* unfinished, int n_flags) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *s = v;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { s[0] = v; s[1] = v; }
     if (unfinished)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_flags; i += gridDim.x * blockDim.x) unfinished[i] = 1;
 }
@@ -180,6 +209,12 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     // write - tok_in, unfinished - it reads with plain loads
     const int cur = scalar_load_int(&a.state->cur_len);      // scalar cache: the logits loads below do not queue behind it
     if (cur >= a.L) return;
+    if (row == 0 && tid == 0) {
+        // the next step's counters: state[1] is read by no workgroup of this launch, state[0] (read above) is written by none
+        a.state[1].pos = scalar_load_int(&a.state->pos) + 1;
+        a.state[1].cur_len = cur + 1;
+        a.state[1].step_count = scalar_load_int(&a.state->step_count) + 1;
+    }
     const float* lg = a.logits + (size_t)row * a.V;
     const float* ug = a.guidance > 1.0f ? a.logits + (size_t)(row + a.rows) * a.V : nullptr;
     for (int v = tid; v < V; v += 256) {
@@ -430,29 +465,15 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         const int feed = (int)(forced == -1 ? nxt : forced);
         a.tok_in[row] = feed;
         if (a.guidance > 1.0f) a.tok_in[row + a.rows] = feed;   // both halves see the same ids (M:2112)
-        // the loop state is advanced by advance_kernel, launched right behind this one: a "last block advances" ticket
+        // the loop state is settled from these latches by a LATER launch (settle_state): a "last block advances" ticket
         // here cost 2 x rows serialised device-scope atomics per step (~8 of this kernel's 13 us at 288 rows)
     }
 }
 
-// one workgroup: counts the rows still unfinished after the selection and advances the loop state
-// (unfinished_sequences.max() == 0 / MaxLengthCriteria of the third-party loop)
+// one workgroup: counts the rows still unfinished after the selection and settles the loop state from the counters the
+// selection left in state[1] (unfinished_sequences.max() == 0 / MaxLengthCriteria of the third-party loop)
 __global__ __launch_bounds__(256) void advance_kernel(StepState* s, const int* unfinished, int rows, int L) {
-    __shared__ int part[4];
-    if (s->cur_len >= L) return;
-    int n = 0;
-    for (int r = threadIdx.x; r < rows; r += 256) n += unfinished[r] ? 1 : 0;
-    n = (int)wave_sum((float)n);              // rows <= 2^24: exact in fp32
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int unf_total = part[0] + part[1] + part[2] + part[3];
-        s->pos += 1;
-        s->cur_len += 1;
-        s->step_count += 1;
-        s->n_unfinished = unf_total;
-        if (unf_total == 0 && s->done_len == 0) s->done_len = s->cur_len;
-    }
+    settle_state(s, unfinished, rows);
 }
 
 // feed tokens for the first decode step: the masked last column of the start ids (M:2107, M:2120-2130)
@@ -555,8 +576,9 @@ __global__ __launch_bounds__(256) void swiglu_frag_kernel(const float* __restric
 }  // namespace
 
 hipError_t embed_codebooks_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s) {
-    if (dtype == PTTS_BF16) hipLaunchKernelGGL(embed_codebooks_kernel<PBF16>, dim3(B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(embed_codebooks_kernel<PF32>, dim3(B), dim3(256), 0, s, a);
+    const int extra = a.unfinished ? 1 : 0;     // one more workgroup settles the loop state
+    if (dtype == PTTS_BF16) hipLaunchKernelGGL(embed_codebooks_kernel<PBF16>, dim3(B + extra), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(embed_codebooks_kernel<PF32>, dim3(B + extra), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t embed_prompt_launch(const EmbedArgs& a, int B, int dtype, hipStream_t s) {

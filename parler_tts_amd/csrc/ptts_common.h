@@ -122,9 +122,12 @@ struct StepState {
 // kernel may read a word this way only if NO launch of that kernel writes it - neither the reading workgroup nor any other
 // workgroup of the same dispatch - and the value was written by an EARLIER dispatch on the same stream (the scalar cache is
 // invalidated at every dispatch boundary, not inside one).  A fused kernel that both advances the loop state and reads it
-// (the reverted merged tail of DESIGN_HISTORY.md) must use plain loads for those words.  Writers today: advance_kernel
-// (StepState), select_kernel (tok_in, unfinished), build_bias_kernel (bias_flag), the host (block_table); readers: the attention,
-// gemm-append, embed and select kernels - never a writer of the word it reads.  `make EXTRA=-DPTTS_PLAIN_STATE_LOADS` (into a scratch copy of the objects)
+// (the reverted merged tail of DESIGN_HISTORY.md) must use plain loads for those words.  The loop state is TWO StepState words
+// apart for exactly this reason: state[0] is what a step's kernels read; state[1] holds the counters (pos, cur_len, step_count)
+// the last selection left for the next step.  Writers today: select_kernel (state[1], tok_in, unfinished - it reads state[0]),
+// advance_kernel and the extra workgroup of embed_codebooks_kernel (state[0] - they read state[1], and so do that launch's
+// embedding workgroups), the prefill kernels (both), build_bias_kernel (bias_flag), the host (block_table); readers: the
+// attention, gemm-append, embed and select kernels - never a launch that writes the word it reads.  `make EXTRA=-DPTTS_PLAIN_STATE_LOADS` (into a scratch copy of the objects)
 // builds the same library with ordinary global loads for an A/B of ids (tests need no change).
 typedef const int __attribute__((address_space(4))) ptts_cint;
 typedef const float __attribute__((address_space(4))) ptts_cfloat;

@@ -2139,6 +2139,110 @@ def test_fused_qkv_attention_free_run_under_graph_replay_and_ragged_finish(hip):
     torch.cuda.empty_cache()
 
 
+def test_deferred_loop_state_equals_the_advance_launch_of_rounds_1_to_5(hip):
+    """Round 6: a replayed step no longer ends with a one-workgroup advance launch.  The selection leaves the next step's counters
+    in state[1] and its EOS latches in `unfinished`; one extra workgroup of the NEXT step's embedding launch settles state[0]
+    from them, and ptts_decode_steps settles it once behind the last replay of a call (csrc/misc.hip settle_state).  Against
+    PTTS_EAGER_ADVANCE=1 (every replay ends with advance_kernel, as in rounds 1-5), at mini_v0.1 widths in bf16:
+    (a) the loop state read at EVERY C-ABI boundary of a walk in calls of 1, 2, 3, 5, 1, 7 ... steps - replays, eager profiled
+        steps and forward / select half steps mixed - with live EOS heads (utterances finish at different steps: n_unfinished
+        falls, done_len is latched once), past max_length (replays clamp), and over a second prefill on the same engine;
+    (b) raw ids of generate(): greedy without EOS over four KV pages, greedy and sampled with live EOS (the pipelined EOS poll
+        decides where the call stops, the Philox draw is keyed by step_count)."""
+    from parler_tts_amd import _hip
+    from parler_tts_amd.configuration import mini_v01_config
+    from parler_tts_amd.delay_pattern import build_delay_pattern_mask
+    from parler_tts_amd.modeling import ParlerTTSForConditionalGeneration
+    from parler_tts_amd.weights import synthetic_state_dict
+
+    cfg = mini_v01_config()
+    cfg.decoder.num_hidden_layers = 2
+    g = torch.Generator().manual_seed(11)
+    B, T, P = 5, 12, 9
+    K = cfg.decoder.num_codebooks
+    enc = torch.randn(B, T, cfg.text_encoder.d_model, generator=g) * 0.3
+    prompt = torch.randint(2, 32000, (B, P), generator=g)
+    dev = "cuda:0"
+
+    def walk(model, L):
+        eng = model.engine(B, T, P, L)
+        trace = []
+        for call in range(2):
+            ids = torch.full((B * K, 1), cfg.decoder.bos_token_id, dtype=torch.long)
+            ids, pattern = build_delay_pattern_mask(ids, cfg.decoder.bos_token_id, cfg.decoder.pad_token_id, L, K)
+            pattern = pattern.to(dev).contiguous()
+            raw = torch.full((B * K, L), cfg.decoder.pad_token_id, dtype=torch.long, device=dev)
+            raw[:, :1] = ids.to(dev)
+            eng.prefill(B, B, enc.to(dev).contiguous(), torch.ones(B, T, dtype=torch.int32, device=dev), prompt.to(dev).contiguous(),
+                        None, pattern, raw, 1)
+            sp = _hip.PttsSampling(0, 1.0, 0, 1.0, 0)
+            st = eng.state()
+            trace.append((st.pos, st.cur_len, st.n_unfinished, st.done_len, st.step_count))
+            sizes = [1, 2, 3, 5, 1, 7, 11, 4]
+            i = 0
+            while st.cur_len < L:
+                n = sizes[i % len(sizes)]
+                if i % 5 == 3:                       # half steps (what user logits processors drive)
+                    eng.forward_step()
+                    eng.select_step(sp)
+                elif i % 7 == 5:                     # a call whose first step is an eager, profiled one
+                    eng.decode_steps(n, sp, profile_every=1)
+                    eng.profile_read()
+                else:
+                    eng.decode_steps(n, sp)
+                if i % 3 == 0:                       # the pipelined poll's view
+                    eng.state_snapshot(0)
+                    ps = eng.state_poll(0)
+                    trace.append(("snap", ps.pos, ps.cur_len, ps.n_unfinished, ps.done_len, ps.step_count))
+                st = eng.state()
+                trace.append((st.pos, st.cur_len, st.n_unfinished, st.done_len, st.step_count))
+                i += 1
+            eng.decode_steps(3, sp)                  # past max_length: nothing moves
+            st = eng.state()
+            trace.append((st.pos, st.cur_len, st.n_unfinished, st.done_len, st.step_count))
+            trace.append(raw.cpu().clone())
+        return trace
+
+    outs = {}
+    for eager in (False, True):
+        if eager:
+            os.environ["PTTS_EAGER_ADVANCE"] = "1"
+        try:
+            for never_eos, L in ((True, 270), (False, 120)):
+                _models.clear()
+                torch.cuda.empty_cache()
+                sd = synthetic_state_dict(cfg, seed=3, never_eos=never_eos, ln_jitter=0.1, parts=("decoder",))
+                model = ParlerTTSForConditionalGeneration(cfg, sd, dtype="bf16", device=dev)
+                model.generate(encoder_outputs=(enc,), prompt_input_ids=prompt, do_sample=False, max_length=L, return_raw_ids=True)
+                runs = [model.last_raw_ids.cpu().clone()]
+                if not never_eos:
+                    model.generate(encoder_outputs=(enc,), prompt_input_ids=prompt, do_sample=True, temperature=0.9, top_k=40,
+                                   max_length=L, return_raw_ids=True, seed=5)
+                    runs.append(model.last_raw_ids.cpu().clone())
+                    runs.append(walk(model, 60))
+                outs[(eager, never_eos)] = runs
+                del model
+        finally:
+            os.environ.pop("PTTS_EAGER_ADVANCE", None)
+    for never_eos in (True, False):
+        a, b = outs[(False, never_eos)], outs[(True, never_eos)]
+        assert a[0].shape == b[0].shape and torch.equal(a[0], b[0]), never_eos
+        if not never_eos:
+            assert a[1].shape == b[1].shape and torch.equal(a[1], b[1])
+            ta, tb = a[2], b[2]
+            assert len(ta) == len(tb)
+            for x, y in zip(ta, tb):
+                if torch.is_tensor(x):
+                    assert torch.equal(x, y)
+                else:
+                    assert x == y, (x, y)
+            states = [x for x in ta if not torch.is_tensor(x) and x[0] != "snap"]
+            assert any(s[3] > 0 for s in states) or min(s[2] for s in states) > 0     # done_len latched iff every row finished
+            assert states[-1][1] == 60 or states[-1][3] > 0
+    assert outs[(False, True)][0].shape[1] == 270
+    torch.cuda.empty_cache()
+
+
 def test_fused_launch_hand_off_failure_is_a_loud_error_not_a_hang(hip):
     """The attention half of the fused launch waits for arrival tags of the projection half with a BOUNDED spin.  If they never come
     (test hook PTTS_FUSED_TEST_BREAK=1: the projection half stores its tags elsewhere) the first workgroups give up after 2 s of
