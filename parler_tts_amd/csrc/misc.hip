@@ -215,8 +215,20 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         a.state[1].cur_len = cur + 1;
         a.state[1].step_count = scalar_load_int(&a.state->step_count) + 1;
     }
+    // what thread 0 needs behind the choice - this row's latch, its delay-pattern value, the forced ids of the tests - does not
+    // depend on the scores: requested here, beside the logits, instead of as two more dependent round trips at the kernel's end
+    // (the row's own words only: no other workgroup of this launch writes them)
+    int unf_in = 0;
+    long long forced_in = -1, force_in = -1, fseq_in = -1;
+    if (tid == 0) {
+        unf_in = a.unfinished[row];
+        forced_in = a.pattern[(size_t)row * a.L + cur];
+        if (a.force) force_in = a.force[row];
+        if (a.force_seq) fseq_in = a.force_seq[(size_t)row * a.L + cur];
+    }
     const float* lg = a.logits + (size_t)row * a.V;
     const float* ug = a.guidance > 1.0f ? a.logits + (size_t)(row + a.rows) * a.V : nullptr;
+    float gbest = -INFINITY; int gbi = 0x7fffffff;
     for (int v = tid; v < V; v += 256) {
         float s = lg[v];
         if (ug) { float u = ug[v]; s = u + (s - u) * a.guidance; }
@@ -224,16 +236,13 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         if (v == a.eos && cur < a.eos_free_until) s = -INFINITY;
         if (a.do_sample && a.temperature != 1.0f) s = s / a.temperature;
         sv[v] = s;
+        if (s > gbest || (s == gbest && v < gbi)) { gbest = s; gbi = v; }   // greedy: the lane's candidate straight from the registers
     }
     __syncthreads();
 
     int choice = 0;
     if (!a.do_sample) {
-        float best = -INFINITY; int bi = 0x7fffffff;
-        for (int v = tid; v < V; v += 256) {
-            float s = sv[v];
-            if (s > best || (s == best && v < bi)) { best = s; bi = v; }
-        }
+        float best = gbest; int bi = gbi;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
@@ -454,14 +463,14 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     if (tid == 0) {
         long long tok = choice;
         if (a.own) a.own[(size_t)row * a.L + cur] = tok;
-        if (a.force && a.force[row] >= 0) tok = a.force[row];   // teacher forcing (tests)
-        if (a.force_seq) { const long long f = a.force_seq[(size_t)row * a.L + cur]; if (f >= 0) tok = f; }
-        const int unf = a.unfinished[row];
+        if (force_in >= 0) tok = force_in;      // teacher forcing (tests)
+        if (fseq_in >= 0) tok = fseq_in;
+        const int unf = unf_in;
         long long nxt = unf ? tok : (long long)a.pad;
         a.raw_ids[(size_t)row * a.L + cur] = nxt;
         const int unf_new = unf && (nxt != (long long)a.eos);
         a.unfinished[row] = unf_new;
-        const long long forced = a.pattern[(size_t)row * a.L + cur];
+        const long long forced = forced_in;
         const int feed = (int)(forced == -1 ? nxt : forced);
         a.tok_in[row] = feed;
         if (a.guidance > 1.0f) a.tok_in[row + a.rows] = feed;   // both halves see the same ids (M:2112)
