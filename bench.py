@@ -847,7 +847,8 @@ def main():
                           + ("fused QKV + self-attention" if fused_ else "self-attention") + " launches)",
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_step": int(chain_bytes), "ms_per_step": round(chain_ms, 4),
-                "launches_per_step": (5 if fused_ else 6) * L_ + 4,
+                # heads, select, embed (+ advance where a replayed step still ends with it: PTTS_EAGER_ADVANCE=1)
+                "launches_per_step": (5 if fused_ else 6) * L_ + (4 if os.environ.get("PTTS_EAGER_ADVANCE") else 3),
                 "derived": "decode loop ms per step (graph replay) minus layers x the sampled average of the dominant launch",
                 "counters": "profiles/r05_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
         if dp is not None:
