@@ -850,7 +850,7 @@ def main():
                 # heads, select, embed (+ advance where a replayed step still ends with it: PTTS_EAGER_ADVANCE=1)
                 "launches_per_step": (5 if fused_ else 6) * L_ + (4 if os.environ.get("PTTS_EAGER_ADVANCE") else 3),
                 "derived": "decode loop ms per step (graph replay) minus layers x the sampled average of the dominant launch",
-                "counters": "profiles/r05_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
+                "counters": "profiles/r06_pmc_decoder_layer.txt (fabric bytes, L2 hit rates, L1->L2 latency, wave-cycle shares per launch)"}
         if dp is not None:
             line["data_parallel"] = dp
             if dp.get("equals_single_gpu") is False:
