@@ -181,7 +181,10 @@ typedef struct ptts_sampling {
  *      Invariant behind those tags (enforced here, stated for completeness): a tag is the cache position + 1, so every pass over
  *      the layers must run at a position of its own within one ptts_prefill .. decode sequence - ptts_decode_steps clamps n_steps
  *      to the columns left, ptts_forward_step refuses a second forward half before its ptts_select_step and at max_length, and
- *      ptts_prefill clears the tags. ---- */
+ *      ptts_prefill clears the tags.
+ *      The loop state a read returns is settled at every return of these calls: inside a run of replayed steps the counters and the
+ *      unfinished-row count of a step are written by the NEXT step's first launch (no launch of their own), and the call ends with
+ *      one settling launch behind its last replay. ---- */
 int ptts_decode_steps(ptts_engine* e, int32_t n_steps, const ptts_sampling* sp, int32_t profile_every, void* stream);
 
 /* One decode step in two halves, for callers that edit the scores in between (custom LogitsProcessor lists,
