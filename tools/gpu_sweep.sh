@@ -1,5 +1,5 @@
 set -o pipefail
-O=gpurun_out/s2h; mkdir -p $O
+O=gpurun_out/${1:-sweep}; mkdir -p $O
 for B in 16 64 128; do
   python3 bench.py --batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-sampling-pass > $O/b$B.json 2> $O/b$B.err || { tail -n 5 $O/b$B.err; exit 1; }
   echo "batch $B done: $(cut -c1-120 $O/b$B.json)"
